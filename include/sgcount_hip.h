@@ -1,0 +1,150 @@
+/*
+ * sgcount_hip.h — C ABI of the MI355X-native sgRNA count path (libsgcount_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of noamteyssier/sgcount v0.1.35.
+ * The reference has no FFI of its own (it is a single Rust binary crate); the
+ * seam these entry points replace is the in-process call
+ *
+ *     Counter::new(reader, &Library, &Option<Permuter>, Offset, size, position_recursion)
+ *                                                   (src/counter.rs:36-66, called at src/count.rs:26-33)
+ *
+ * plus the accessors the callers consume (src/counter.rs:71-76, :239-251).
+ * INTEGRATION.md shows the Rust `extern "C"` block a maintainer would add to
+ * bind them.  Conventions: 0 = OK, negative = error (sgc_last_error() holds a
+ * thread-local message); no exceptions or aborts cross the ABI; every buffer
+ * is caller-owned; plain pointers and sizes only.
+ *
+ * Division of labour (BASELINE.json north_star): the host streams FASTQ and
+ * 2-bit-packs each read's guide window into one record (sgc_pack_reads_host,
+ * or on-device from raw bytes with sgc_sample_push_reads / _push_fastq); the
+ * device does the per-read offset scan (Centered / +1 / -1 windows), the
+ * library lookup, the unambiguous single-mismatch probe and the count.
+ */
+#ifndef SGCOUNT_HIP_H
+#define SGCOUNT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGC_OK 0
+#define SGC_E_ARG (-1)          /* bad argument */
+#define SGC_E_HIP (-2)          /* HIP runtime error / no device */
+#define SGC_E_UNSUPPORTED (-3)  /* library the device path cannot represent (non-ACGT bytes, L > 30) */
+#define SGC_E_DUPLICATE (-4)    /* duplicate library sequence — src/library.rs:91-96 panics */
+#define SGC_E_STATE (-5)        /* call order (no library set, sample finished, ...) */
+#define SGC_E_OOM (-6)
+
+#define SGC_MEM_HOST 0          /* pointer is host memory (pinned or pageable) */
+#define SGC_MEM_DEVICE 1        /* pointer is device memory on the ctx's device */
+
+#define SGC_MAX_GUIDE_LEN 30    /* L + 2 flanking bases must fit one 64-bit word */
+#define SGC_REC8_MAX_LEN 23     /* up to here a read packs into ONE u64 (sgc_record_bytes() == 8) */
+
+typedef struct sgc_ctx sgc_ctx;        /* stands for (&Library, &Option<Permuter>) — src/count.rs:87,103-107 */
+typedef struct sgc_sample sgc_sample;  /* stands for one Counter — src/counter.rs:17-21 */
+
+/* Per-kernel device timing of the last pushes (HIP events on the ctx stream). */
+typedef struct {
+    uint64_t launches;       /* kernel launches accumulated since the last reset */
+    double   lookup_ms;      /* Σ duration of the lookup/count kernel(s) */
+    double   hist_ms;        /* Σ duration of the histogram kernel(s), 0 if fused */
+    double   pack_ms;        /* Σ duration of the on-device pack kernel(s) */
+} sgc_timing;
+
+typedef struct {
+    uint32_t n_guides;
+    uint32_t guide_len;
+    uint32_t record_bytes;     /* 8 or 16 */
+    uint32_t one_mismatch;     /* 1 if the permute table is resident */
+    uint64_t lib_slots;        /* open-addressed slots of the library table */
+    uint64_t perm_slots;       /* slots of the single-mismatch (permute) table, 0 if exact */
+    uint64_t perm_entries;     /* unambiguous children stored (src/permutes.rs map.len(), ACGT children only) */
+    uint64_t table_bytes;      /* device bytes of both tables */
+} sgc_lib_info;
+
+/* ---- context: device + library tables -------------------------------------------------------- */
+
+/* Opens `device`, creates the ctx's stream.  Replaces nothing upstream (the reference has no device). */
+int sgc_init(int device, sgc_ctx **out);
+void sgc_free(sgc_ctx *);
+
+/* Run everything on a caller-supplied hipStream_t instead of the ctx's own (NULL restores it). */
+int sgc_set_stream(sgc_ctx *, void *hip_stream);
+void *sgc_get_stream(sgc_ctx *);
+
+/* Library::from_reader (src/library.rs:17-21,89-99) + Permuter::new (src/permutes.rs:47-75) unless
+ * enable_1mm == 0 (the reference's -x/--exact, src/count.rs:103-107).  seqs = n rows of L ASCII bytes
+ * in library-file order.  Builds the device tables once; they are read-only afterwards and shared by
+ * every sample of the ctx.  SGC_E_DUPLICATE mirrors the duplicate-sequence panic; SGC_E_UNSUPPORTED
+ * is returned for sequences with bytes outside ACGT or L > SGC_MAX_GUIDE_LEN (the caller must fail
+ * loudly: there is no CPU fallback behind this ABI). */
+int sgc_set_library(sgc_ctx *, const uint8_t *seqs, uint32_t n, uint32_t L, int enable_1mm);
+int sgc_library_info(sgc_ctx *, sgc_lib_info *out);
+
+/* Point lookups against the resident tables (Library::contains src/library.rs:34-40 and
+ * Permuter::contains src/permutes.rs:55-57 followed by Library::alias, as at src/counter.rs:111-117).
+ * tokens = n rows of L ASCII bytes; gid_out[i] = guide index (library order) or -1.
+ * which: 0 = library only, 1 = permuter only, 2 = library then permuter. */
+int sgc_lookup(sgc_ctx *, const uint8_t *tokens, uint64_t n, int which, int32_t *gid_out);
+
+/* ---- packing: read -> record ------------------------------------------------------------------ */
+
+/* Bytes per packed record for guide length L: 8 (L <= 23), 16 (L <= 30), 0 = unsupported. */
+uint32_t sgc_record_bytes(uint32_t L);
+
+/* Host packer (pure CPU; usable without a GPU).  Applies Counter::apply_trim / bounds
+ * (src/counter.rs:144-204) for all of Centered / Plus / Minus at once: read i is
+ * seqs[offsets[i] .. offsets[i+1]).  reverse = Offset::Reverse (src/offsetter.rs:10-15).
+ * position_recursion = 0 packs the Centered window only (Position::Null, src/counter.rs:44-48). */
+int sgc_pack_reads_host(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, uint32_t L, int reverse,
+                        uint32_t offset, int position_recursion, void *records_out);
+
+/* ---- one sample = one Counter ------------------------------------------------------------------ */
+
+/* Counter::new's (Offset, position_recursion) — src/counter.rs:36-43.  size is the library's L. */
+int sgc_sample_begin(sgc_ctx *, sgc_sample **out, int reverse, uint32_t offset, int position_recursion);
+
+/* The fold of Counter::count (src/counter.rs:211-236) over n packed records.  Asynchronous on the
+ * ctx stream; a host buffer may be reused after sgc_sample_sync(). */
+int sgc_sample_push_packed(sgc_sample *, const void *records, uint64_t n, int where);
+
+/* Same, from raw read bytes: the device packs (pack kernel) then counts. */
+int sgc_sample_push_reads(sgc_sample *, const uint8_t *seqs, const uint64_t *offsets, uint64_t n, int where);
+
+/* Same, from a chunk of FASTQ text holding whole 4-line records: the device finds the record
+ * boundaries, packs and counts.  n_records_out may be NULL. */
+int sgc_sample_push_fastq(sgc_sample *, const uint8_t *text, uint64_t n_bytes, int where, uint64_t *n_records_out);
+
+int sgc_sample_sync(sgc_sample *);
+
+/* Counter::get_value for every guide + total_reads / matched_reads (src/counter.rs:71-76,239-246).
+ * counts has n_guides entries in library order (the host pools guides that share an id, mirroring
+ * the id-keyed fold at src/counter.rs:232-235).  Synchronises. May be called repeatedly. */
+int sgc_sample_finish(sgc_sample *, uint64_t *counts, uint64_t *total_reads, uint64_t *matched_reads);
+
+/* Device pointer to the sample's u64 count vector (n_guides entries), valid after
+ * sgc_sample_flush(); lets a multi-GPU host hand the vector to RCCL without a host round trip. */
+int sgc_sample_flush(sgc_sample *);
+void *sgc_sample_device_counts(sgc_sample *);
+
+/* Zero the sample's counts / totals (reuse between bench steps). */
+int sgc_sample_reset(sgc_sample *);
+void sgc_sample_free(sgc_sample *);
+
+/* Tuning knobs ("variant": count-kernel variant). */
+int sgc_set_option(sgc_ctx *, const char *key, int64_t value);
+
+/* ---- diagnostics -------------------------------------------------------------------------------- */
+int sgc_timing_enable(sgc_ctx *, int on);     /* record HIP events around every kernel (adds a sync at read) */
+int sgc_timing_read(sgc_ctx *, sgc_timing *out, int reset);
+const char *sgc_last_error(void);
+const char *sgc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

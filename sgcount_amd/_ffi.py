@@ -1,0 +1,86 @@
+"""ctypes binding of libsgcount_hip.so (the C ABI in include/sgcount_hip.h).
+
+Fails loudly: if the shared library is missing and cannot be built, or a call returns an
+error code, an exception is raised — there is no CPU fallback for the count path.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+OK, E_ARG, E_HIP, E_UNSUPPORTED, E_DUPLICATE, E_STATE, E_OOM = 0, -1, -2, -3, -4, -5, -6
+MEM_HOST, MEM_DEVICE = 0, 1
+
+
+class SgcError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"sgcount_hip error {code}: {msg}")
+        self.code = code
+
+
+class Timing(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("lookup_ms", C.c_double), ("hist_ms", C.c_double),
+                ("pack_ms", C.c_double)]
+
+
+class LibInfo(C.Structure):
+    _fields_ = [("n_guides", C.c_uint32), ("guide_len", C.c_uint32), ("record_bytes", C.c_uint32),
+                ("one_mismatch", C.c_uint32), ("lib_slots", C.c_uint64), ("perm_slots", C.c_uint64),
+                ("perm_entries", C.c_uint64), ("table_bytes", C.c_uint64)]
+
+
+# every symbol include/sgcount_hip.h declares: name -> (restype, argtypes)
+_vp, _u8p, _u64, _u32, _i = C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+SYMBOLS = {
+    "sgc_init": (_i, [_i, C.POINTER(_vp)]),
+    "sgc_free": (None, [_vp]),
+    "sgc_set_stream": (_i, [_vp, _vp]),
+    "sgc_get_stream": (_vp, [_vp]),
+    "sgc_set_library": (_i, [_vp, _u8p, _u32, _u32, _i]),
+    "sgc_library_info": (_i, [_vp, C.POINTER(LibInfo)]),
+    "sgc_lookup": (_i, [_vp, _u8p, _u64, _i, _vp]),
+    "sgc_record_bytes": (_u32, [_u32]),
+    "sgc_pack_reads_host": (_i, [_u8p, _vp, _u64, _u32, _i, _u32, _i, _vp]),
+    "sgc_sample_begin": (_i, [_vp, C.POINTER(_vp), _i, _u32, _i]),
+    "sgc_sample_push_packed": (_i, [_vp, _vp, _u64, _i]),
+    "sgc_sample_push_reads": (_i, [_vp, _u8p, _vp, _u64, _i]),
+    "sgc_sample_push_fastq": (_i, [_vp, _u8p, _u64, _i, C.POINTER(_u64)]),
+    "sgc_sample_sync": (_i, [_vp]),
+    "sgc_sample_finish": (_i, [_vp, _vp, C.POINTER(_u64), C.POINTER(_u64)]),
+    "sgc_sample_flush": (_i, [_vp]),
+    "sgc_sample_device_counts": (_vp, [_vp]),
+    "sgc_sample_reset": (_i, [_vp]),
+    "sgc_sample_free": (None, [_vp]),
+    "sgc_set_option": (_i, [_vp, C.c_char_p, C.c_int64]),
+    "sgc_timing_enable": (_i, [_vp, _i]),
+    "sgc_timing_read": (_i, [_vp, C.POINTER(Timing), _i]),
+    "sgc_last_error": (C.c_char_p, []),
+    "sgc_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load():
+    """Loads (building first if needed) libsgcount_hip.so and binds every ABI symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    so = _build.SO
+    if _build.needs_build():
+        so = _build.build()
+    if not os.path.exists(so):
+        raise ImportError(f"{so} is missing: the HIP extension is required (no CPU fallback)")
+    lib = C.CDLL(so)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != OK:
+        raise SgcError(rc, load().sgc_last_error().decode("utf-8", "replace"))
+    return rc

@@ -1,0 +1,447 @@
+// sgc_api.cpp — the C ABI declared in include/sgcount_hip.h (libsgcount_hip.so).
+//
+// Owns device memory, the stream, the library tables and per-sample count vectors.  Every entry point
+// returns an error code; nothing throws across the boundary.  There is deliberately NO CPU fallback for
+// the count path: without a HIP device sgc_init() fails and the caller must surface that.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/sgcount_hip.h"
+#include "sgc_format.h"
+#include "sgc_kernels.h"
+#include "sgc_tables.h"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(e_ == hipErrorOutOfMemory ? SGC_E_OOM : SGC_E_HIP,                     \
+                        std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+    } while (0)
+
+enum { T_LOOKUP = 0, T_HIST = 1, T_PACK = 2, T_KINDS = 3 };
+
+struct sgc_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // library
+    bool has_lib = false, one_mm = false, rec16 = false;
+    uint32_t n = 0, L = 0;
+    uint64_t *d_lib_slots = nullptr, *d_perm_slots = nullptr;
+    uint32_t *d_lib_vals = nullptr, *d_perm_vals = nullptr;
+    sgc_table_view v_lib{}, v_perm{};
+    uint64_t perm_entries = 0;
+    // scratch (grown on demand, stream-ordered reuse)
+    void *d_stage = nullptr; size_t stage_cap = 0;      // host -> device staging of pushed buffers
+    void *d_aux = nullptr; size_t aux_cap = 0;          // offsets / secondary staging
+    uint64_t *d_recs = nullptr; size_t recs_cap = 0;    // records produced by the on-device packers
+    // options
+    int variant = -1;           // count kernel variant; -1 = default
+    // timing
+    bool timing = false;
+    struct span_ev { hipEvent_t a, b; int kind; };
+    std::vector<span_ev> pending;
+    std::vector<hipEvent_t> free_events;
+    sgc_timing acc{};
+};
+
+struct sgc_sample {
+    sgc_ctx *ctx = nullptr;
+    int reverse = 0; uint32_t offset = 0; int recursion = 1;
+    uint32_t *d_c32 = nullptr;
+    unsigned long long *d_c64 = nullptr;
+    unsigned long long *d_matched = nullptr;
+    uint64_t total = 0;
+    uint64_t since_fold = 0;     // reads counted into d_c32 since the last fold (u32 overflow guard)
+};
+
+// ---- helpers -------------------------------------------------------------------------------------
+
+static int ensure(void **p, size_t *cap, size_t need) {
+    if (need <= *cap) return SGC_OK;
+    const size_t want = std::max(need, *cap * 2);
+    if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; *cap = 0; }
+    HIP_TRY(hipMalloc(p, want));
+    *cap = want;
+    return SGC_OK;
+}
+
+static hipEvent_t ev_get(sgc_ctx *c) {
+    if (!c->free_events.empty()) { hipEvent_t e = c->free_events.back(); c->free_events.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+static void timing_drain(sgc_ctx *c) {
+    for (auto &s : c->pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            if (s.kind == T_LOOKUP) c->acc.lookup_ms += ms;
+            else if (s.kind == T_HIST) c->acc.hist_ms += ms;
+            else c->acc.pack_ms += ms;
+            c->acc.launches++;
+        }
+        c->free_events.push_back(s.a);
+        c->free_events.push_back(s.b);
+    }
+    c->pending.clear();
+}
+
+struct timed {
+    sgc_ctx *c; int kind; hipEvent_t a = nullptr, b = nullptr;
+    timed(sgc_ctx *c_, int k) : c(c_), kind(k) {
+        if (!c->timing) return;
+        a = ev_get(c); b = ev_get(c);
+        if (a && b) hipEventRecord(a, c->stream);
+    }
+    ~timed() {
+        if (!c->timing || !a || !b) return;
+        hipEventRecord(b, c->stream);
+        c->pending.push_back({a, b, kind});
+        if (c->pending.size() >= 256) timing_drain(c);
+    }
+};
+
+static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
+    sgc_ctx *c = s->ctx;
+    // u32 device counters: fold into the u64 vector before any counter could wrap
+    if (s->since_fold + n > 0xFFFFFFF0ull) {
+        sgc_launch_fold(c->stream, s->d_c32, s->d_c64, c->n);
+        s->since_fold = 0;
+    }
+    uint64_t done = 0;
+    while (done < n) {
+        const uint64_t chunk = std::min<uint64_t>(n - done, 0xF0000000ull);
+        const uint64_t *p = d_recs + done * (c->rec16 ? 2 : 1);
+        {
+            timed t(c, T_LOOKUP);
+            sgc_launch_count_direct(c->stream, p, chunk, c->L, c->rec16, c->v_lib, c->v_perm, c->one_mm, s->d_c32,
+                                    s->d_matched);
+        }
+        HIP_TRY(hipGetLastError());
+        done += chunk;
+        s->since_fold += chunk;
+        if (done < n) { sgc_launch_fold(c->stream, s->d_c32, s->d_c64, c->n); s->since_fold = 0; }
+    }
+    s->total += n;
+    return SGC_OK;
+}
+
+// ---- ABI -------------------------------------------------------------------------------------------
+
+extern "C" {
+
+const char *sgc_last_error(void) { return g_err.c_str(); }
+const char *sgc_version(void) { return "sgcount_hip 0.1.0 (gfx950)"; }
+
+uint32_t sgc_record_bytes(uint32_t L) {
+    if (L == 0 || L > SGC_MAXL) return 0;
+    return L <= SGC_REC8_MAXL ? 8 : 16;
+}
+
+int sgc_init(int device, sgc_ctx **out) {
+    if (!out) return fail(SGC_E_ARG, "sgc_init: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(SGC_E_HIP, std::string("sgc_init: no HIP device available (") + hipGetErrorString(e) +
+                                   "); the count path has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(SGC_E_ARG, "sgc_init: device index out of range");
+    HIP_TRY(hipSetDevice(device));
+    sgc_ctx *c = new (std::nothrow) sgc_ctx();
+    if (!c) return fail(SGC_E_OOM, "sgc_init: out of host memory");
+    c->device = device;
+    e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(SGC_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    c->stream = c->own_stream;
+    if (const char *v = getenv("SGC_VARIANT")) c->variant = atoi(v);
+    *out = c;
+    return SGC_OK;
+}
+
+static void free_tables(sgc_ctx *c) {
+    if (c->d_lib_slots) hipFree(c->d_lib_slots);
+    if (c->d_perm_slots) hipFree(c->d_perm_slots);
+    if (c->d_lib_vals) hipFree(c->d_lib_vals);
+    if (c->d_perm_vals) hipFree(c->d_perm_vals);
+    c->d_lib_slots = c->d_perm_slots = nullptr;
+    c->d_lib_vals = c->d_perm_vals = nullptr;
+    c->has_lib = false;
+}
+
+void sgc_free(sgc_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    timing_drain(c);
+    for (auto e : c->free_events) hipEventDestroy(e);
+    free_tables(c);
+    if (c->d_stage) hipFree(c->d_stage);
+    if (c->d_aux) hipFree(c->d_aux);
+    if (c->d_recs) hipFree(c->d_recs);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int sgc_set_stream(sgc_ctx *c, void *hip_stream) {
+    if (!c) return fail(SGC_E_ARG, "sgc_set_stream: ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return SGC_OK;
+}
+
+void *sgc_get_stream(sgc_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
+    if (!c || !key) return fail(SGC_E_ARG, "sgc_set_option: NULL argument");
+    if (!strcmp(key, "variant")) { c->variant = (int)value; return SGC_OK; }
+    return fail(SGC_E_ARG, std::string("sgc_set_option: unknown key ") + key);
+}
+
+static int upload_table(const sgc_host_table &h, uint64_t **d_slots, uint32_t **d_vals, sgc_table_view *v,
+                        hipStream_t st) {
+    const size_t nslots = h.slots.size();
+    HIP_TRY(hipMalloc((void **)d_slots, nslots * sizeof(uint64_t)));
+    HIP_TRY(hipMemcpyAsync(*d_slots, h.slots.data(), nslots * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    if (h.gid_bits == 0) {
+        HIP_TRY(hipMalloc((void **)d_vals, nslots * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpyAsync(*d_vals, h.vals.data(), nslots * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    v->slots = *d_slots; v->vals = *d_vals; v->log2_slots = h.log2_slots; v->gid_bits = h.gid_bits;
+    return SGC_OK;
+}
+
+int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int enable_1mm) {
+    if (!c || !seqs) return fail(SGC_E_ARG, "sgc_set_library: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_tables(c);
+    std::vector<uint64_t> keys;
+    sgc_host_table h_lib, h_perm;
+    std::string err;
+    int rc = sgc_build_library_table(seqs, n, L, keys, h_lib, err);
+    if (rc != SGC_OK) return fail(rc, "sgc_set_library: " + err);
+    rc = upload_table(h_lib, &c->d_lib_slots, &c->d_lib_vals, &c->v_lib, c->stream);
+    if (rc != SGC_OK) { free_tables(c); return rc; }
+    c->v_perm = sgc_table_view{nullptr, nullptr, 0, h_lib.gid_bits};
+    c->perm_entries = 0;
+    if (enable_1mm) {
+        sgc_build_permute_table(keys, L, h_lib, h_perm);
+        rc = upload_table(h_perm, &c->d_perm_slots, &c->d_perm_vals, &c->v_perm, c->stream);
+        if (rc != SGC_OK) { free_tables(c); return rc; }
+        c->perm_entries = h_perm.entries;
+    }
+    c->n = n; c->L = L; c->one_mm = enable_1mm != 0; c->rec16 = L > SGC_REC8_MAXL; c->has_lib = true;
+    return SGC_OK;
+}
+
+int sgc_library_info(sgc_ctx *c, sgc_lib_info *out) {
+    if (!c || !out) return fail(SGC_E_ARG, "sgc_library_info: NULL argument");
+    if (!c->has_lib) return fail(SGC_E_STATE, "sgc_library_info: no library set");
+    memset(out, 0, sizeof(*out));
+    out->n_guides = c->n; out->guide_len = c->L; out->record_bytes = c->rec16 ? 16 : 8;
+    out->one_mismatch = c->one_mm;
+    out->lib_slots = 1ull << c->v_lib.log2_slots;
+    out->perm_slots = c->one_mm ? 1ull << c->v_perm.log2_slots : 0;
+    out->perm_entries = c->perm_entries;
+    const uint64_t per = c->v_lib.gid_bits ? 8 : 12;
+    out->table_bytes = (out->lib_slots + out->perm_slots) * per;
+    return SGC_OK;
+}
+
+int sgc_lookup(sgc_ctx *c, const uint8_t *tokens, uint64_t n, int which, int32_t *gid_out) {
+    if (!c || (!tokens && n) || (!gid_out && n)) return fail(SGC_E_ARG, "sgc_lookup: NULL argument");
+    if (!c->has_lib) return fail(SGC_E_STATE, "sgc_lookup: no library set");
+    if (which < 0 || which > 2) return fail(SGC_E_ARG, "sgc_lookup: which must be 0, 1 or 2");
+    if (n == 0) return SGC_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<uint64_t> keys(n);
+    for (uint64_t i = 0; i < n; i++)
+        if (!sgc_pack_key(tokens + i * c->L, c->L, keys[i])) keys[i] = SGC_EMPTY;   // non-ACGT token: no match
+    int rc = ensure(&c->d_stage, &c->stage_cap, n * 8);
+    if (rc) return rc;
+    rc = ensure(&c->d_aux, &c->aux_cap, n * 4);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_stage, keys.data(), n * 8, hipMemcpyHostToDevice, c->stream));
+    sgc_launch_lookup(c->stream, (const uint64_t *)c->d_stage, n, c->v_lib, c->v_perm, which, c->one_mm,
+                      (int32_t *)c->d_aux);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(gid_out, c->d_aux, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SGC_OK;
+}
+
+int sgc_pack_reads_host(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, uint32_t L, int reverse,
+                        uint32_t offset, int position_recursion, void *records_out) {
+    if ((!seqs && n) || !offsets || (!records_out && n)) return fail(SGC_E_ARG, "sgc_pack_reads_host: NULL argument");
+    const uint32_t rb = sgc_record_bytes(L);
+    if (!rb) return fail(SGC_E_UNSUPPORTED, "sgc_pack_reads_host: guide length outside 1..30");
+    uint64_t *out = (uint64_t *)records_out;
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t span, status;
+        sgc_pack_one(seqs + offsets[i], offsets[i + 1] - offsets[i], L, reverse, offset, position_recursion, span,
+                     status);
+        if (rb == 16) { out[2 * i] = span; out[2 * i + 1] = status; }
+        else out[i] = span | (status << (2 * (L + 2)));
+    }
+    return SGC_OK;
+}
+
+int sgc_sample_begin(sgc_ctx *c, sgc_sample **out, int reverse, uint32_t offset, int position_recursion) {
+    if (!c || !out) return fail(SGC_E_ARG, "sgc_sample_begin: NULL argument");
+    *out = nullptr;
+    if (!c->has_lib) return fail(SGC_E_STATE, "sgc_sample_begin: no library set");
+    HIP_TRY(hipSetDevice(c->device));
+    sgc_sample *s = new (std::nothrow) sgc_sample();
+    if (!s) return fail(SGC_E_OOM, "sgc_sample_begin: out of host memory");
+    s->ctx = c; s->reverse = reverse != 0; s->offset = offset; s->recursion = position_recursion != 0;
+    hipError_t e = hipMalloc((void **)&s->d_c32, (size_t)c->n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_c64, (size_t)c->n * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_matched, 8);
+    if (e != hipSuccess) { sgc_sample_free(s); return fail(SGC_E_OOM, std::string("sgc_sample_begin: ") + hipGetErrorString(e)); }
+    int rc = sgc_sample_reset(s);
+    if (rc) { sgc_sample_free(s); return rc; }
+    *out = s;
+    return SGC_OK;
+}
+
+int sgc_sample_reset(sgc_sample *s) {
+    if (!s) return fail(SGC_E_ARG, "sgc_sample_reset: NULL");
+    sgc_ctx *c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(s->d_c32, 0, (size_t)c->n * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(s->d_c64, 0, (size_t)c->n * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(s->d_matched, 0, 8, c->stream));
+    s->total = 0; s->since_fold = 0;
+    return SGC_OK;
+}
+
+void sgc_sample_free(sgc_sample *s) {
+    if (!s) return;
+    hipSetDevice(s->ctx->device);
+    hipStreamSynchronize(s->ctx->stream);
+    if (s->d_c32) hipFree(s->d_c32);
+    if (s->d_c64) hipFree(s->d_c64);
+    if (s->d_matched) hipFree(s->d_matched);
+    delete s;
+}
+
+int sgc_sample_push_packed(sgc_sample *s, const void *records, uint64_t n, int where) {
+    if (!s || (!records && n)) return fail(SGC_E_ARG, "sgc_sample_push_packed: NULL argument");
+    if (n == 0) return SGC_OK;
+    sgc_ctx *c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = (size_t)n * (c->rec16 ? 16 : 8);
+    const uint64_t *d = (const uint64_t *)records;
+    if (where == SGC_MEM_HOST) {
+        int rc = ensure(&c->d_stage, &c->stage_cap, bytes);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(c->d_stage, records, bytes, hipMemcpyHostToDevice, c->stream));
+        d = (const uint64_t *)c->d_stage;
+    } else if (where != SGC_MEM_DEVICE) {
+        return fail(SGC_E_ARG, "sgc_sample_push_packed: where must be SGC_MEM_HOST or SGC_MEM_DEVICE");
+    }
+    return count_records(s, d, n);
+}
+
+int sgc_sample_push_reads(sgc_sample *s, const uint8_t *seqs, const uint64_t *offsets, uint64_t n, int where) {
+    if (!s || !offsets) return fail(SGC_E_ARG, "sgc_sample_push_reads: NULL argument");
+    if (n == 0) return SGC_OK;
+    sgc_ctx *c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint8_t *d_seqs = seqs; const uint64_t *d_off = offsets;
+    if (where == SGC_MEM_HOST) {
+        const uint64_t nbytes = offsets[n];
+        int rc = ensure(&c->d_stage, &c->stage_cap, nbytes ? nbytes : 1);
+        if (rc) return rc;
+        rc = ensure(&c->d_aux, &c->aux_cap, (n + 1) * 8);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(c->d_stage, seqs, nbytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_aux, offsets, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        d_seqs = (const uint8_t *)c->d_stage; d_off = (const uint64_t *)c->d_aux;
+    } else if (where != SGC_MEM_DEVICE) {
+        return fail(SGC_E_ARG, "sgc_sample_push_reads: where must be SGC_MEM_HOST or SGC_MEM_DEVICE");
+    }
+    void *p = c->d_recs; size_t cap = c->recs_cap;
+    int rc = ensure(&p, &cap, (size_t)n * (c->rec16 ? 16 : 8));
+    c->d_recs = (uint64_t *)p; c->recs_cap = cap;
+    if (rc) return rc;
+    {
+        timed t(c, T_PACK);
+        sgc_launch_pack_reads(c->stream, d_seqs, d_off, n, c->L, c->rec16, s->reverse, s->offset, s->recursion,
+                              c->d_recs);
+    }
+    HIP_TRY(hipGetLastError());
+    return count_records(s, c->d_recs, n);
+}
+
+int sgc_sample_push_fastq(sgc_sample *s, const uint8_t *text, uint64_t n_bytes, int where, uint64_t *n_records_out) {
+    (void)s; (void)text; (void)n_bytes; (void)where; (void)n_records_out;
+    return fail(SGC_E_UNSUPPORTED, "sgc_sample_push_fastq: not built yet");
+}
+
+int sgc_sample_sync(sgc_sample *s) {
+    if (!s) return fail(SGC_E_ARG, "sgc_sample_sync: NULL");
+    HIP_TRY(hipSetDevice(s->ctx->device));
+    HIP_TRY(hipStreamSynchronize(s->ctx->stream));
+    return SGC_OK;
+}
+
+int sgc_sample_flush(sgc_sample *s) {
+    if (!s) return fail(SGC_E_ARG, "sgc_sample_flush: NULL");
+    sgc_ctx *c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    sgc_launch_fold(c->stream, s->d_c32, s->d_c64, c->n);
+    HIP_TRY(hipGetLastError());
+    s->since_fold = 0;
+    return SGC_OK;
+}
+
+void *sgc_sample_device_counts(sgc_sample *s) { return s ? (void *)s->d_c64 : nullptr; }
+
+int sgc_sample_finish(sgc_sample *s, uint64_t *counts, uint64_t *total_reads, uint64_t *matched_reads) {
+    if (!s) return fail(SGC_E_ARG, "sgc_sample_finish: NULL");
+    sgc_ctx *c = s->ctx;
+    int rc = sgc_sample_flush(s);
+    if (rc) return rc;
+    unsigned long long m = 0;
+    if (counts) HIP_TRY(hipMemcpyAsync(counts, s->d_c64, (size_t)c->n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&m, s->d_matched, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (total_reads) *total_reads = s->total;
+    if (matched_reads) *matched_reads = m;
+    return SGC_OK;
+}
+
+int sgc_timing_enable(sgc_ctx *c, int on) {
+    if (!c) return fail(SGC_E_ARG, "sgc_timing_enable: NULL");
+    c->timing = on != 0;
+    return SGC_OK;
+}
+
+int sgc_timing_read(sgc_ctx *c, sgc_timing *out, int reset) {
+    if (!c || !out) return fail(SGC_E_ARG, "sgc_timing_read: NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    timing_drain(c);
+    *out = c->acc;
+    if (reset) c->acc = sgc_timing{};
+    return SGC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+// sgc_format.h — packed-record and key formats shared by host code and gfx950 kernels.
+//
+// A *record* is everything Counter::assign (reference src/counter.rs:96-140) needs from one read:
+// the L+2 oriented bases covering the Minus / Centered / Plus windows, and one status code that
+// folds in the bounds rule (src/counter.rs:158-180) and the non-ACGT bytes.
+//
+//   span  = oriented bases [o-1, o+L+1)      (oriented = forward read, or its reverse complement)
+//   M = span[0..L)   C = span[1..L+1)   P = span[2..L+2)
+//   base code: A=0 C=1 G=2 T=3, 2 bits each, span base w at bits [2w, 2w+2); non-ACGT bases store 0
+//
+//   per-window state s in [0, L+2):  0 = clean (all ACGT, in bounds)
+//                                    1 = dead  (cannot match: out of bounds, >=2 non-ACGT bytes, or a
+//                                               single non-ACGT byte that is not 'N')
+//                                    2+j = exactly one non-ACGT byte, an 'N', at window position j
+//   status = sC + K*(sP + K*sM),  K = L+2
+//
+// Bounds: a window that fails Counter::bounds makes the reference return None for the whole read
+// (src/counter.rs:105-108), which is the same as that window and every later stage being dead, so
+// the packer marks them dead (Centered fails => all three; Plus fails => Plus and Minus).
+//
+//   rec8  (L <= 23): one u64 = span bits [0, 2K) | status << 2K     (2K + 14 <= 64 since (L+2)^3 <= 2^14)
+//   rec16 (L <= 30): u64 span, u64 status
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SGC_HD __host__ __device__ __forceinline__
+#else
+#define SGC_HD inline
+#endif
+
+#define SGC_REC8_MAXL 23
+#define SGC_MAXL 30
+#define SGC_STATE_CLEAN 0u
+#define SGC_STATE_DEAD 1u
+#define SGC_NONE 0xFFFFFFFFu
+#define SGC_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+// byte -> code: 0..3 = ACGT, 4 = 'N', 5 = anything else
+SGC_HD uint32_t sgc_base_code(uint8_t c) {
+    switch (c) {
+        case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3;
+        case 'N': return 4; default: return 5;
+    }
+}
+
+// Reverse strand: the reference slices Record::seq_rev_comp() (src/counter.rs:196-204).  fxread's
+// complement of a non-ACGT byte is not pinned by any upstream test; it is restated (oracle/
+// sgcount_oracle.c ctr_trim) as a byte that is neither ACGT nor 'N', i.e. code 5.
+SGC_HD uint32_t sgc_base_code_rc(uint8_t c) {
+    switch (c) {
+        case 'A': return 3; case 'C': return 2; case 'G': return 1; case 'T': return 0;
+        default: return 5;
+    }
+}
+
+SGC_HD uint64_t sgc_key_mask(uint32_t L) { return L >= 32 ? ~0ull : ((1ull << (2 * L)) - 1ull); }
+
+SGC_HD uint64_t sgc_hash(uint64_t key) {
+    // multiplicative (Fibonacci) hash with a fold so that low key bits reach the top
+    key ^= key >> 29;
+    return key * 0x9E3779B97F4A7C15ull;
+}
+
+struct sgc_table_view {
+    const uint64_t *slots;   // packed: (key << gid_bits) | gid, SGC_EMPTY if free; split: key or SGC_EMPTY
+    const uint32_t *vals;    // split layout only: gid per slot
+    uint32_t log2_slots;
+    uint32_t gid_bits;       // 0 => split layout
+};
+
+// Builds one record from a read.  `emit(span_bits, status)` style is avoided to keep this usable in
+// kernels: returns span and status through references.
+SGC_HD void sgc_pack_one(const uint8_t *seq, uint64_t n, uint32_t L, int reverse, uint32_t o, int recursion,
+                         uint64_t &span, uint64_t &status) {
+    const uint32_t K = L + 2;
+    // window bounds (src/counter.rs:158-180); all arithmetic in u64 like the reference's usize
+    const bool c_ok = (uint64_t)o + L <= n;
+    const bool p_ok = c_ok && recursion && ((uint64_t)o + 1 + L <= n);
+    const bool m_ok = p_ok && o >= 1;
+    span = 0;
+    uint32_t ninv[3] = {0, 0, 0};   // index 0 = M, 1 = C, 2 = P
+    uint32_t st[3] = {0, 0, 0};
+    bool bad[3] = {false, false, false};
+    if (c_ok) {
+        for (uint32_t w = 0; w < K; w++) {
+            const int64_t p = (int64_t)o - 1 + (int64_t)w;
+            if (p < 0 || (uint64_t)p >= n) continue;      // only reachable for windows already out of bounds
+            const uint8_t b = reverse ? seq[n - 1 - (uint64_t)p] : seq[p];
+            const uint32_t code = reverse ? sgc_base_code_rc(b) : sgc_base_code(b);
+            if (code < 4) { span |= (uint64_t)code << (2 * w); continue; }
+            // span base w sits at window position w (M), w-1 (C), w-2 (P)
+            for (int k = 0; k < 3; k++) {
+                const int32_t j = (int32_t)w - k;
+                if (j < 0 || j >= (int32_t)L) continue;
+                ninv[k]++;
+                if (code == 4) st[k] = 2u + (uint32_t)j; else bad[k] = true;
+            }
+        }
+    }
+    const bool ok[3] = {m_ok, c_ok, p_ok};
+    for (int k = 0; k < 3; k++) {
+        if (!ok[k] || ninv[k] >= 2 || bad[k]) st[k] = SGC_STATE_DEAD;
+        else if (ninv[k] == 0) st[k] = SGC_STATE_CLEAN;
+    }
+    status = (uint64_t)st[1] + (uint64_t)K * ((uint64_t)st[2] + (uint64_t)K * (uint64_t)st[0]);
+}

@@ -1,0 +1,112 @@
+// sgc_tables.cpp — host-side construction of the library and single-mismatch tables.
+#include "sgc_tables.h"
+
+#include <algorithm>
+#include <utility>
+
+#include "../../include/sgcount_hip.h"
+
+bool sgc_pack_key(const uint8_t *seq, uint32_t L, uint64_t &key) {
+    key = 0;
+    for (uint32_t j = 0; j < L; j++) {
+        const uint32_t c = sgc_base_code(seq[j]);
+        if (c > 3) return false;
+        key |= (uint64_t)c << (2 * j);
+    }
+    return true;
+}
+
+static uint32_t ceil_log2(uint64_t x) {
+    uint32_t l = 0;
+    while ((1ull << l) < x) l++;
+    return l;
+}
+
+static void table_alloc(sgc_host_table &t, uint64_t entries, double max_load, uint32_t gid_bits) {
+    uint64_t want = (uint64_t)((double)entries / max_load) + 1;
+    t.log2_slots = std::max<uint32_t>(4, ceil_log2(want));
+    t.gid_bits = gid_bits;
+    t.slots.assign(1ull << t.log2_slots, SGC_EMPTY);
+    if (gid_bits == 0) t.vals.assign(1ull << t.log2_slots, SGC_NONE); else t.vals.clear();
+    t.entries = 0;
+}
+
+static inline void table_insert(sgc_host_table &t, uint64_t key, uint32_t gid) {
+    const uint64_t mask = (1ull << t.log2_slots) - 1;
+    uint64_t h = sgc_hash(key) >> (64 - t.log2_slots);
+    while (t.slots[h] != SGC_EMPTY) h = (h + 1) & mask;
+    if (t.gid_bits) t.slots[h] = (key << t.gid_bits) | gid;
+    else { t.slots[h] = key; t.vals[h] = gid; }
+    t.entries++;
+}
+
+static inline uint32_t table_find_host(const sgc_host_table &t, uint64_t key) {
+    const uint64_t mask = (1ull << t.log2_slots) - 1;
+    uint64_t h = sgc_hash(key) >> (64 - t.log2_slots);
+    for (;;) {
+        const uint64_t s = t.slots[h];
+        if (s == SGC_EMPTY) return SGC_NONE;
+        if (t.gid_bits) { if ((s >> t.gid_bits) == key) return (uint32_t)(s & ((1ull << t.gid_bits) - 1)); }
+        else if (s == key) return t.vals[h];
+        h = (h + 1) & mask;
+    }
+}
+
+// gid field width for the packed layout, or 0 if (key, gid) does not fit one u64
+static uint32_t choose_gid_bits(uint32_t n, uint32_t L) {
+    const uint32_t room = 64 - 2 * L;
+    const uint32_t gb = std::min<uint32_t>(room, 32);
+    if (gb == 0) return 0;
+    // the all-ones gid is reserved so that a full slot can never equal SGC_EMPTY
+    if (gb < 32 && (uint64_t)n > (1ull << gb) - 1) return 0;
+    return gb;
+}
+
+int sgc_build_library_table(const uint8_t *seqs, uint32_t n, uint32_t L, std::vector<uint64_t> &keys,
+                            sgc_host_table &out, std::string &err) {
+    if (L == 0 || L > SGC_MAXL) { err = "guide length " + std::to_string(L) + " outside 1.." + std::to_string(SGC_MAXL); return SGC_E_UNSUPPORTED; }
+    if (n == 0) { err = "empty library"; return SGC_E_ARG; }
+    keys.resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (!sgc_pack_key(seqs + (size_t)i * L, L, keys[i])) {
+            err = "library sequence " + std::to_string(i) + " has bytes outside ACGT";
+            return SGC_E_UNSUPPORTED;
+        }
+    }
+    table_alloc(out, n, 0.4, choose_gid_bits(n, L));
+    for (uint32_t i = 0; i < n; i++) {
+        if (table_find_host(out, keys[i]) != SGC_NONE) {      // src/library.rs:91-96
+            err = "Unexpected duplicate sequence in library found: " + std::string((const char *)seqs + (size_t)i * L, L);
+            return SGC_E_DUPLICATE;
+        }
+        table_insert(out, keys[i], i);
+    }
+    return SGC_OK;
+}
+
+void sgc_build_permute_table(const std::vector<uint64_t> &keys, uint32_t L, const sgc_host_table &lib,
+                             sgc_host_table &out) {
+    const uint32_t n = (uint32_t)keys.size();
+    const uint32_t gb = lib.gid_bits;
+    // all (child, parent) pairs: 3 ACGT substitutions per position (src/permutes.rs:78-107 minus the 'N' column)
+    std::vector<std::pair<uint64_t, uint32_t>> kids;
+    kids.reserve((size_t)n * 3 * L);
+    for (uint32_t g = 0; g < n; g++) {
+        const uint64_t k = keys[g];
+        for (uint32_t j = 0; j < L; j++)
+            for (uint64_t d = 1; d < 4; d++) kids.emplace_back(k ^ (d << (2 * j)), g);
+    }
+    std::sort(kids.begin(), kids.end());
+    // keep children with exactly one parent that are not library members (src/permutes.rs:127-144: a
+    // second sighting moves the child to `null`; a parent is in `null` from the start)
+    std::vector<std::pair<uint64_t, uint32_t>> keep;
+    keep.reserve(kids.size());
+    for (size_t i = 0; i < kids.size();) {
+        size_t j = i + 1;
+        while (j < kids.size() && kids[j].first == kids[i].first) j++;
+        if (j - i == 1 && table_find_host(lib, kids[i].first) == SGC_NONE) keep.push_back(kids[i]);
+        i = j;
+    }
+    table_alloc(out, keep.size(), 0.5, gb);
+    for (const auto &kv : keep) table_insert(out, kv.first, kv.second);
+}

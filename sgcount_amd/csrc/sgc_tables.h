@@ -1,0 +1,31 @@
+// sgc_tables.h — host-side construction of the device hash tables.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "sgc_format.h"
+
+struct sgc_host_table {
+    std::vector<uint64_t> slots;
+    std::vector<uint32_t> vals;   // split layout only
+    uint32_t log2_slots = 0;
+    uint32_t gid_bits = 0;        // 0 => split layout
+    uint64_t entries = 0;
+};
+
+// Packs an ASCII guide (ACGT only) into a 2-bit key, base j at bits [2j, 2j+2).  Returns false on other bytes.
+bool sgc_pack_key(const uint8_t *seq, uint32_t L, uint64_t &key);
+
+// Library::table_from_reader (reference src/library.rs:89-99).  Returns 0, or SGC_E_DUPLICATE /
+// SGC_E_UNSUPPORTED (include/sgcount_hip.h) with `err` set.
+int sgc_build_library_table(const uint8_t *seqs, uint32_t n, uint32_t L, std::vector<uint64_t> &keys,
+                            sgc_host_table &out, std::string &err);
+
+// Permuter::build (reference src/permutes.rs:63-75,127-158) restricted to what Counter::assign can
+// observe: child -> the UNIQUE guide at Hamming distance 1; children that are library members or have
+// two or more parents are dropped.  Only ACGT substitutions are stored; the 'N' children are resolved
+// in-kernel by probing the library (sgc_kernels.hip window_assign).
+void sgc_build_permute_table(const std::vector<uint64_t> &keys, uint32_t L, const sgc_host_table &lib,
+                             sgc_host_table &out);

@@ -1,0 +1,269 @@
+"""Parity tests proper: the HIP path (through the C ABI, via the host mirror) against the reference's
+known answers, the committed golden vectors and the CPU oracle.  Bit-exact: this is integer work.
+
+Run on the GPU box with:  python -m pytest tests -m gpu
+"""
+import collections
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    import sgcount_amd
+    sgcount_amd._ffi.load()
+    return sgcount_amd
+
+
+def _lib(S, text):
+    return S.Library.from_reader(S.parse_fastx(text))
+
+
+def _fasta(seqs, prefix=b"g"):
+    return b"".join(b">%s%d\n%s\n" % (prefix, i, s) for i, s in enumerate(seqs))
+
+
+def _reads_fasta(reads):
+    return b"".join(b">r%d\n%s\n" % (i, r) for i, r in enumerate(reads))
+
+
+# ---- the reference's own unit tests, through the ABI --------------------------------------------
+LIB_ACTG = b">seq.0\nACTG\n"
+
+
+@pytest.mark.parametrize("pack", ["host", "device"])
+def test_counter_kats(S, pack):
+    """counter.rs:283-320"""
+    lib = _lib(S, LIB_ACTG)
+    perm = S.Permuter.new(lib.keys())
+
+    def run(read, p):
+        return S.Counter.new(S.parse_fastx(b">seq.0\n" + read + b"\n"), lib, p, S.Offset.Forward(0), 4, False, pack=pack)
+
+    assert run(b"ACTG", None).get_value(b"seq.0") == 1          # count_no_distance_no_permute
+    assert run(b"AGTG", None).get_value(b"seq.0") == 0          # count_no_distance_with_permute / with_distance_no_permute
+    c = run(b"AGTG", perm)                                       # count_with_distance_with_permute
+    assert c.get_value(b"seq.0") == 1 and c.total_reads() == 1 and c.matched_reads() == 1
+
+
+def test_permuter_kats(S):
+    """permutes.rs:193-253 via sgc_lookup(which=1): child → unique parent"""
+    p = S.Permuter.new([b"ACTG"])
+    truth = [b"AATG", b"ACGG", b"ACAG", b"TCTG", b"GCTG", b"AGTG", b"ACTC", b"ATTG", b"ACCG", b"ACTT", b"CCTG", b"ACTA"]
+    assert all(p.contains(t) == b"ACTG" for t in truth)
+    assert p.contains(b"ACTG") is None                          # parents live in `null`
+    p = S.Permuter.new([b"AC", b"CG"])
+    for t in (b"GC", b"TC", b"AA", b"AT"):
+        assert p.contains(t) == b"AC"
+    for t in (b"CA", b"CT", b"GG", b"TG"):
+        assert p.contains(t) == b"CG"
+    for t in (b"AG", b"CG", b"CC", b"AC"):
+        assert p.contains(t) is None
+    assert p._device().info().perm_entries == 8                 # the 12 of permutes.rs:215 minus the 4 'N' children
+
+
+def test_permuter_n_children_via_counter(S):
+    """permutes.rs:196-199 'N' children (ACNG, NCTG, ANTG, ACTN → ACTG) are resolved in-kernel"""
+    lib = _lib(S, LIB_ACTG)
+    perm = S.Permuter.new(lib.keys())
+    for child in (b"ACNG", b"NCTG", b"ANTG", b"ACTN"):
+        c = S.Counter.new(S.parse_fastx(b">r\n" + child + b"\n"), lib, perm, S.Offset.Forward(0), 4, False)
+        assert c.get_value(b"seq.0") == 1, child
+    lib2 = _lib(S, b">a\nAC\n>b\nCG\n")
+    perm2 = S.Permuter.new(lib2.keys())
+    want = {b"NC": b"a", b"AN": b"a", b"CN": b"b", b"NG": b"b"}
+    for child, ident in want.items():
+        c = S.Counter.new(S.parse_fastx(b">r\n" + child + b"\n"), lib2, perm2, S.Offset.Forward(0), 2, False)
+        assert c.get_value(ident) == 1 and c.matched_reads() == 1, child
+
+
+def test_library_kats(S):
+    """library.rs:119-136"""
+    lib = _lib(S, LIB_ACTG)
+    assert lib.size() == 4 and len(list(lib.keys())) == 1
+    dev = lib.device(False)
+    assert dev.lookup([b"ACTG", b"ACTT"], which=0).tolist() == [0, -1]
+    with pytest.raises(RuntimeError):
+        _lib(S, b">seq.0\nACTG\n>seq.1\nACTG\n")
+    # the ABI itself reports duplicates too (SGC_E_DUPLICATE)
+    bad = S.Library({b"ACTG": b"x"}, [b"ACTG", b"ACTG"])
+    with pytest.raises(RuntimeError):
+        bad.device(False)
+
+
+def test_unsupported_library_fails_loudly(S):
+    ffi = S._ffi
+    with pytest.raises(ffi.SgcError) as e:
+        _lib(S, b">a\nACNG\n").device(True)
+    assert e.value.code == ffi.E_UNSUPPORTED
+    with pytest.raises(ffi.SgcError) as e:
+        _lib(S, b">a\n" + b"A" * 31 + b"\n").device(False)
+    assert e.value.code == ffi.E_UNSUPPORTED
+
+
+# ---- example/ fixtures vs committed golden tables -------------------------------------------------
+@pytest.mark.parametrize("pack", ["host", "device"])
+def test_example_fixtures_golden(S, pack, example_library_text, example_reads):
+    g = json.load(open(os.path.join(GOLDEN, "example_counts.json")))
+    lib = _lib(S, example_library_text)
+    perm = S.Permuter.new(lib.keys())
+    for c in g["cases"]:
+        reads = example_reads[c["file"][:-9]]
+        ctr = S.Counter.new(S.parse_fastx(reads), lib, None if c["exact"] else perm, S.Offset.Forward(g["offset"]),
+                            lib.size(), c["position_recursion"], pack=pack)
+        assert ctr.guide_counts().tolist() == c["counts"], c["file"]
+        assert ctr.total_reads() == c["total"] and ctr.matched_reads() == c["matched"]
+        assert [ctr.get_value(i) for i in lib.values()] == c["counts"]
+
+
+@pytest.mark.parametrize("pack", ["host", "device"])
+def test_edge_cases_golden(S, pack):
+    """Hand-made and seeded cases: N / lowercase / IUPAC bytes, short and empty reads, offset 0,
+    reverse strand, ambiguity, REC8 max length (23) and REC16 lengths (24, 30)."""
+    g = json.load(open(os.path.join(GOLDEN, "edge_cases.json")))
+    libs = {}
+    for c in g["cases"]:
+        key = tuple(c["guides"])
+        if key not in libs:
+            libs[key] = _lib(S, _fasta([s.encode() for s in c["guides"]]))
+        lib = libs[key]
+        perm = None if c["exact"] else S.Permuter.new(lib.keys())
+        off = S.Offset.Reverse(c["offset"]) if c["reverse"] else S.Offset.Forward(c["offset"])
+        reads = [S.Record(b"r", r.encode("latin1")) for r in c["reads"]]
+        ctr = S.Counter.new(iter(reads), lib, perm, off, lib.size(), c["position_recursion"], pack=pack)
+        want = collections.Counter(a for a in c["assign"] if a >= 0)
+        got = {i: v for i, v in enumerate(ctr.guide_counts().tolist()) if v}
+        assert got == dict(want), (c["name"], c["exact"], c["position_recursion"])
+        assert ctr.total_reads() == len(reads) and ctr.matched_reads() == sum(want.values())
+
+
+def test_edge_cases_per_read(S):
+    """Each golden read on its own: pins the per-read assignment, not only the totals."""
+    g = json.load(open(os.path.join(GOLDEN, "edge_cases.json")))
+    for c in g["cases"]:
+        if not c["name"].startswith("handmade"):
+            continue
+        lib = _lib(S, _fasta([s.encode() for s in c["guides"]]))
+        perm = None if c["exact"] else S.Permuter.new(lib.keys())
+        off = S.Offset.Reverse(c["offset"]) if c["reverse"] else S.Offset.Forward(c["offset"])
+        for r, a in zip(c["reads"], c["assign"]):
+            ctr = S.Counter.new(iter([S.Record(b"r", r.encode("latin1"))]), lib, perm, off, lib.size(),
+                                c["position_recursion"])
+            got = [i for i, v in enumerate(ctr.guide_counts().tolist()) if v]
+            assert got == ([a] if a >= 0 else []), (c["name"], r, c["exact"], c["position_recursion"])
+
+
+# ---- seeded random inputs vs the oracle ------------------------------------------------------------
+def _random_case(rng, L, n_guides, n_reads, o):
+    alpha = b"ACGT"
+    guides, seen = [], set()
+    while len(guides) < n_guides:
+        if guides and rng.random() < 0.15:        # plant Hamming-1/2 neighbours
+            s = bytearray(rng.choice(guides))
+            for _ in range(rng.choice([1, 2])):
+                s[rng.randrange(L)] = rng.choice(alpha)
+            s = bytes(s)
+        else:
+            s = bytes(rng.choice(alpha) for _ in range(L))
+        if s not in seen:
+            seen.add(s); guides.append(s)
+    reads = []
+    for _ in range(n_reads):
+        g = bytearray(rng.choice(guides))
+        u = rng.random()
+        if u < 0.2:
+            g[rng.randrange(L)] = rng.choice(b"ACGTN")
+        elif u < 0.25:
+            g[rng.randrange(L)] = rng.choice(b"ACGTN"); g[rng.randrange(L)] = rng.choice(b"ACGTNa")
+        elif u < 0.3:
+            g = bytearray(rng.choice(alpha) for _ in range(L))
+        pre_len = o + rng.choice([0, 0, 0, 1, -1, 2])
+        pre = bytes(rng.choice(alpha) for _ in range(max(pre_len, 0)))
+        tail = bytes(rng.choice(alpha) for _ in range(rng.choice([0, 1, 2, 5, 30])))
+        r = pre + bytes(g) + tail
+        if rng.random() < 0.03:
+            r = r[: rng.randrange(len(r) + 1)]
+        reads.append(r)
+    return guides, reads
+
+
+@pytest.mark.parametrize("L,n_guides", [(20, 2000), (12, 300), (23, 500), (27, 400)])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_random_vs_oracle(S, L, n_guides, reverse):
+    rng = random.Random(1000 * L + n_guides + reverse)
+    o = 9
+    guides, reads = _random_case(rng, L, n_guides, 20000, o)
+    if reverse:
+        reads = [bytes((c ^ 4) if (c & 2) else (c ^ 21) for c in reversed(r)) if rng.random() < 0.97 else r
+                 for r in reads]
+    lib_text, reads_text = _fasta(guides), _reads_fasta(reads)
+    lib = _lib(S, lib_text)
+    perm = S.Permuter.new(lib.keys())
+    off = S.Offset.Reverse(o) if reverse else S.Offset.Forward(o)
+    for exact in (False, True):
+        for recursion in (True, False):
+            want, tot, mat = O.count_text(lib_text, reads_text, reverse, o, exact, recursion)
+            for pack in ("host", "device"):
+                ctr = S.Counter.new(S.parse_fastx(reads_text), lib, None if exact else perm, off, L, recursion,
+                                    pack=pack, batch=7001)
+                assert ctr.guide_counts().tolist() == want, (exact, recursion, pack)
+                assert (ctr.total_reads(), ctr.matched_reads()) == (tot, mat)
+                assert int(ctr.guide_counts().sum()) == mat
+
+
+def test_duplicate_ids_pool_counts(S):
+    """counter.rs:232-235 folds by id: two guides sharing an id report the pooled count on both rows"""
+    lib_text = b">same\nACGTAC\n>same\nTTGCAA\n>other\nCCCCCC\n"
+    reads = _reads_fasta([b"ACGTAC", b"ACGTAC", b"TTGCAA", b"CCCCCC"])
+    lib = _lib(S, lib_text)
+    ctr = S.Counter.new(S.parse_fastx(reads), lib, None, S.Offset.Forward(0), 6, False)
+    want, _, _ = O.count_text(lib_text, reads, False, 0, True, False)
+    assert [ctr.get_value(i) for i in lib.values()] == want == [3, 3, 1]
+
+
+def test_empty_and_zero_reads(S):
+    lib = _lib(S, LIB_ACTG)
+    c = S.Counter.new(iter([]), lib, None, S.Offset.Forward(0), 4, True)
+    assert c.total_reads() == 0 and c.matched_reads() == 0 and c.fraction_mapped() != c.fraction_mapped()
+    c = S.Counter.new(iter([S.Record(b"r", b"")] * 5), lib, S.Permuter.new(lib.keys()), S.Offset.Forward(0), 4, True)
+    assert c.total_reads() == 5 and c.matched_reads() == 0
+
+
+def test_device_resident_push_and_accumulation(S):
+    """Pushing device-resident records in several batches == one batch (linearity of the fold)."""
+    import ctypes as C
+    import torch
+    rng = random.Random(5)
+    guides, reads = _random_case(rng, 20, 500, 30000, 4)
+    lib = _lib(S, _fasta(guides))
+    dev = lib.device(True)
+    ffi, L = S._ffi, dev.lib
+    recs = S.pack_reads_host(reads, 20, S.Offset.Forward(4), True)
+    d = torch.from_numpy(recs.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+
+    def run(splits):
+        smp = C.c_void_p()
+        ffi.check(L.sgc_sample_begin(dev.ctx, C.byref(smp), 0, 4, 1))
+        bounds = [0] + splits + [len(reads)]
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            ffi.check(L.sgc_sample_push_packed(smp, d.data_ptr() + 8 * a, b - a, ffi.MEM_DEVICE))
+        out = np.zeros(len(guides), dtype=np.uint64)
+        t, m = C.c_uint64(), C.c_uint64()
+        ffi.check(L.sgc_sample_finish(smp, out.ctypes.data, C.byref(t), C.byref(m)))
+        L.sgc_sample_free(smp)
+        return out.tolist(), t.value, m.value
+
+    one = run([])
+    assert one == run([1, 64, 65, 10000, 29999])
+    want, tot, mat = O.count_text(_fasta(guides), _reads_fasta(reads), False, 4, False, True)
+    assert one == (want, tot, mat)
