@@ -61,6 +61,26 @@ SYMBOLS = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One process may hold only ONE HIP/ROCr runtime (a second one cannot open the KFD device and
+    reports "no HIP GPUs").  PyTorch wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7);
+    libsgcount_hip.so needs libamdhip64.so.7 too.  Loading torch's copy first (without importing torch)
+    lets the dynamic loader satisfy our DT_NEEDED by SONAME and lets a later `import torch` find the
+    same file, so both sides share one runtime.  Hosts without torch (C++/Rust) use /opt/rocm's."""
+    if os.environ.get("SGC_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Loads (building first if needed) libsgcount_hip.so and binds every ABI symbol."""
     global _lib
@@ -71,6 +91,7 @@ def load():
         so = _build.build()
     if not os.path.exists(so):
         raise ImportError(f"{so} is missing: the HIP extension is required (no CPU fallback)")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(so)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol

@@ -46,13 +46,11 @@ SGC_HD uint32_t sgc_base_code(uint8_t c) {
 }
 
 // Reverse strand: the reference slices Record::seq_rev_comp() (src/counter.rs:196-204).  fxread's
-// complement of a non-ACGT byte is not pinned by any upstream test; it is restated (oracle/
-// sgcount_oracle.c ctr_trim) as a byte that is neither ACGT nor 'N', i.e. code 5.
+// complement is not pinned by any upstream test; it is restated (oracle/sgcount_oracle.c ctr_trim) as
+// the byte trick `c & 2 ? c ^ 4 : c ^ 21` (A<->T, C<->G; 'N' -> 'J', and 'J' -> 'N'), and the
+// complemented byte is then classified exactly like a forward byte.
 SGC_HD uint32_t sgc_base_code_rc(uint8_t c) {
-    switch (c) {
-        case 'A': return 3; case 'C': return 2; case 'G': return 1; case 'T': return 0;
-        default: return 5;
-    }
+    return sgc_base_code((c & 2) ? (uint8_t)(c ^ 4) : (uint8_t)(c ^ 21));
 }
 
 SGC_HD uint64_t sgc_key_mask(uint32_t L) { return L >= 32 ? ~0ull : ((1ull << (2 * L)) - 1ull); }

@@ -55,7 +55,7 @@ def test_init_fails_loudly_without_gpu():
 def test_host_packer_matches_python_restatement(L, reverse):
     import sgcount_amd as S
     rng = random.Random(L * 2 + reverse)
-    alpha = b"ACGT" * 6 + b"Nn" + b"R"
+    alpha = b"ACGT" * 6 + b"NnJ" + b"R"
     for o in (0, 1, 3):
         for recursion in (True, False):
             reads = []
