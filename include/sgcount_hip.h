@@ -103,6 +103,11 @@ uint32_t sgc_record_bytes(uint32_t L);
 int sgc_pack_reads_host(const uint8_t *seqs, const uint64_t *offsets, uint64_t n, uint32_t L, int reverse,
                         uint32_t offset, int position_recursion, void *records_out);
 
+/* Device packer on caller buffers: raw read bytes (device) -> records (device), the same bits as
+ * sgc_pack_reads_host.  Asynchronous on the ctx stream.  Needs a library (for L). */
+int sgc_pack_reads_device(sgc_ctx *, const uint8_t *d_seqs, const uint64_t *d_offsets, uint64_t n, int reverse,
+                          uint32_t offset, int position_recursion, void *d_records_out);
+
 /* ---- one sample = one Counter ------------------------------------------------------------------ */
 
 /* Counter::new's (Offset, position_recursion) — src/counter.rs:36-43.  size is the library's L. */
@@ -130,6 +135,9 @@ int sgc_sample_finish(sgc_sample *, uint64_t *counts, uint64_t *total_reads, uin
  * sgc_sample_flush(); lets a multi-GPU host hand the vector to RCCL without a host round trip. */
 int sgc_sample_flush(sgc_sample *);
 void *sgc_sample_device_counts(sgc_sample *);
+/* Flush, then copy the u64 count vector followed by {total_reads, matched_reads} (n_guides + 2 words)
+ * into a caller-owned DEVICE buffer, asynchronously on the ctx stream (the RCCL hand-off). */
+int sgc_sample_export_device(sgc_sample *, uint64_t *d_out);
 
 /* Zero the sample's counts / totals (reuse between bench steps). */
 int sgc_sample_reset(sgc_sample *);

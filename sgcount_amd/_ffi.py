@@ -41,6 +41,7 @@ SYMBOLS = {
     "sgc_lookup": (_i, [_vp, _u8p, _u64, _i, _vp]),
     "sgc_record_bytes": (_u32, [_u32]),
     "sgc_pack_reads_host": (_i, [_u8p, _vp, _u64, _u32, _i, _u32, _i, _vp]),
+    "sgc_pack_reads_device": (_i, [_vp, _vp, _vp, _u64, _i, _u32, _i, _vp]),
     "sgc_sample_begin": (_i, [_vp, C.POINTER(_vp), _i, _u32, _i]),
     "sgc_sample_push_packed": (_i, [_vp, _vp, _u64, _i]),
     "sgc_sample_push_reads": (_i, [_vp, _u8p, _vp, _u64, _i]),
@@ -49,6 +50,7 @@ SYMBOLS = {
     "sgc_sample_finish": (_i, [_vp, _vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "sgc_sample_flush": (_i, [_vp]),
     "sgc_sample_device_counts": (_vp, [_vp]),
+    "sgc_sample_export_device": (_i, [_vp, _vp]),
     "sgc_sample_reset": (_i, [_vp]),
     "sgc_sample_free": (None, [_vp]),
     "sgc_set_option": (_i, [_vp, C.c_char_p, C.c_int64]),

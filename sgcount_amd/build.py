@@ -1,7 +1,10 @@
-"""Builds libsgcount_hip.so (C ABI + gfx950 kernels) in-tree with hipcc.
+"""Builds the in-tree native libraries with hipcc for gfx950:
 
-hipcc cross-compiles for gfx950 without a GPU; the built .so travels to the GPU box with the
-repo snapshot (it is git-ignored, not gpurun-ignored).
+  libsgcount_hip.so    C ABI + count/pack kernels   (include/sgcount_hip.h)
+  libsgcount_synth.so  synthetic workload generator (include/sgcount_synth.h; bench/tests only)
+
+hipcc cross-compiles for gfx950 without a GPU; the built .so files travel to the GPU box with the
+repo snapshot (they are git-ignored, not gpurun-ignored).
 """
 import os
 import shutil
@@ -10,34 +13,51 @@ import sys
 
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
+INC = os.path.join(os.path.dirname(PKG), "include")
 SO = os.path.join(PKG, "libsgcount_hip.so")
-SOURCES = ["sgc_api.cpp", "sgc_tables.cpp", "sgc_kernels.hip"]
-HEADERS = ["sgc_format.h", "sgc_kernels.h", "sgc_tables.h", os.path.join("..", "..", "include", "sgcount_hip.h")]
+SYNTH_SO = os.path.join(PKG, "libsgcount_synth.so")
+
+TARGETS = {
+    SO: (["sgc_api.cpp", "sgc_tables.cpp", "sgc_kernels.hip"],
+         ["sgc_format.h", "sgc_kernels.h", "sgc_tables.h", os.path.join(INC, "sgcount_hip.h")]),
+    SYNTH_SO: (["sgc_synth.hip"], ["sgc_format.h", "sgc_synth.h", os.path.join(INC, "sgcount_synth.h")]),
+}
 
 
 def _hipcc():
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
             return cand
-    raise RuntimeError("hipcc not found: cannot build libsgcount_hip.so (no CPU fallback exists)")
+    raise RuntimeError("hipcc not found: cannot build the HIP libraries (no CPU fallback exists)")
 
 
-def needs_build():
-    if not os.path.exists(SO):
+def _deps(so):
+    srcs, hdrs = TARGETS[so]
+    return [os.path.join(CSRC, f) for f in srcs + hdrs] + [os.path.abspath(__file__)]
+
+
+def needs_build(so=SO):
+    if not os.path.exists(so):
         return True
-    t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    t = os.path.getmtime(so)
+    return any(os.path.getmtime(d) > t for d in _deps(so) if os.path.exists(d))
 
 
-def build(force=False, verbose=False):
-    if not force and not needs_build():
-        return SO
+def build_one(so, force=False, verbose=False):
+    if not force and not needs_build(so):
+        return so
+    srcs, _ = TARGETS[so]
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-result", "-Wno-unused-value", "-o", SO] + [os.path.join(CSRC, f) for f in SOURCES]
+           "-Wno-unused-result", "-Wno-unused-value", "-o", so] + [os.path.join(CSRC, f) for f in srcs]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
+    return so
+
+
+def build(force=False, verbose=False):
+    for so in TARGETS:
+        build_one(so, force, verbose)
     return SO
 
 

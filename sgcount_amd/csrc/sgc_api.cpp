@@ -302,6 +302,21 @@ int sgc_pack_reads_host(const uint8_t *seqs, const uint64_t *offsets, uint64_t n
     return SGC_OK;
 }
 
+int sgc_pack_reads_device(sgc_ctx *c, const uint8_t *d_seqs, const uint64_t *d_offsets, uint64_t n, int reverse,
+                          uint32_t offset, int position_recursion, void *d_records_out) {
+    if (!c || !d_offsets || (!d_records_out && n)) return fail(SGC_E_ARG, "sgc_pack_reads_device: NULL argument");
+    if (!c->has_lib) return fail(SGC_E_STATE, "sgc_pack_reads_device: no library set");
+    if (n == 0) return SGC_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    {
+        timed t(c, T_PACK);
+        sgc_launch_pack_reads(c->stream, d_seqs, d_offsets, n, c->L, c->rec16, reverse != 0, offset,
+                              position_recursion != 0, (uint64_t *)d_records_out);
+    }
+    HIP_TRY(hipGetLastError());
+    return SGC_OK;
+}
+
 int sgc_sample_begin(sgc_ctx *c, sgc_sample **out, int reverse, uint32_t offset, int position_recursion) {
     if (!c || !out) return fail(SGC_E_ARG, "sgc_sample_begin: NULL argument");
     *out = nullptr;
@@ -413,6 +428,17 @@ int sgc_sample_flush(sgc_sample *s) {
 }
 
 void *sgc_sample_device_counts(sgc_sample *s) { return s ? (void *)s->d_c64 : nullptr; }
+
+int sgc_sample_export_device(sgc_sample *s, uint64_t *d_out) {
+    if (!s || !d_out) return fail(SGC_E_ARG, "sgc_sample_export_device: NULL");
+    sgc_ctx *c = s->ctx;
+    int rc = sgc_sample_flush(s);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_out, s->d_c64, (size_t)c->n * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_out + c->n, &s->total, 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_out + c->n + 1, s->d_matched, 8, hipMemcpyDeviceToDevice, c->stream));
+    return SGC_OK;
+}
 
 int sgc_sample_finish(sgc_sample *s, uint64_t *counts, uint64_t *total_reads, uint64_t *matched_reads) {
     if (!s) return fail(SGC_E_ARG, "sgc_sample_finish: NULL");

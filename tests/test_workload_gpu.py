@@ -1,0 +1,82 @@
+"""GPU: synthetic generator host == device, device packer == host packer, and the synthetic
+workload counted on the GPU == the CPU oracle on the same reads (bit-exact)."""
+import numpy as np
+import pytest
+
+import _oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import sgcount_amd as S
+    from sgcount_amd import synth, workload
+    S._ffi.load()
+    return torch, S, synth, workload
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_generator_device_matches_host(env, mode):
+    torch, S, synth, _ = env
+    lib = synth.library(3000, 20)
+    lib_dev = torch.from_numpy(lib).cuda()
+    raw, offs = synth.reads_device(lib_dev, 12345, 50000, mode=mode)
+    h_raw, h_offs = synth.reads_host(lib, 12345, 50000, mode=mode)
+    assert np.array_equal(offs.cpu().numpy().astype(np.uint64), h_offs)
+    assert np.array_equal(raw.cpu().numpy(), h_raw)
+    fq, _ = synth.fastq_device(lib_dev, 999_999_990, 2000, mode=mode)      # crosses a digit-count boundary
+    assert fq.cpu().numpy().tobytes() == synth.fastq_host(lib, 999_999_990, 2000, mode=mode)
+
+
+@pytest.mark.parametrize("L,reverse,recursion", [(20, False, True), (20, True, True), (20, False, False), (27, False, True)])
+def test_device_packer_matches_host_packer(env, L, reverse, recursion):
+    torch, S, synth, workload = env
+    import ctypes as C
+    lib_seqs, library = workload.synth_library(2000, L)
+    h_raw, h_offs = synth.reads_host(lib_seqs, 0, 40000, mode=1)
+    reads = [h_raw[int(h_offs[i]):int(h_offs[i + 1])].tobytes() for i in range(40000)]
+    # sprinkle non-ACGT bytes
+    rng = np.random.default_rng(3)
+    raw = h_raw.copy()
+    idx = rng.integers(0, len(raw), 4000)
+    raw[idx] = rng.choice(np.frombuffer(b"NNNnRJ", dtype=np.uint8), 4000)
+    reads = [raw[int(h_offs[i]):int(h_offs[i + 1])].tobytes() for i in range(40000)]
+    off = S.Offset.Reverse(30) if reverse else S.Offset.Forward(30)
+    want = S.pack_reads_host(reads, L, off, recursion)
+    dl = library.device(False)
+    d_raw = torch.from_numpy(raw).cuda()
+    d_offs = torch.from_numpy(h_offs.astype(np.int64)).cuda()
+    out = torch.empty(len(want), dtype=torch.int64, device="cuda")
+    dl.set_stream(torch.cuda.current_stream().cuda_stream)
+    S._ffi.check(dl.lib.sgc_pack_reads_device(dl.ctx, d_raw.data_ptr(), d_offs.data_ptr(), 40000, int(reverse), 30,
+                                              int(recursion), out.data_ptr()))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+
+
+@pytest.mark.parametrize("exact", [False, True])
+def test_synthetic_workload_vs_oracle_2m(env, exact):
+    """2M reads of the bench workload (10k guides so that the hot guides are really hot) vs the oracle."""
+    torch, S, synth, workload = env
+    n, ng = 2_000_000, 10_000
+    wl = workload.DeviceWorkload(n, ng, 20, one_mismatch=not exact, gen_chunk=700_000)
+    wl.step()
+    counts, total, matched = wl.result()
+    lib_text = synth.library_fasta(wl.lib_seqs)
+    lib = O.Library(lib_text)
+    ctr = O.Counter(lib, None if exact else O.Permuter(lib), False, 30, 20, True)
+    for first in range(0, n, 500_000):
+        ctr.feed_text(synth.fastq_host(wl.lib_seqs, first, 500_000))
+    assert total == n == ctr.total_reads()
+    assert matched == ctr.matched_reads()
+    assert counts.tolist() == ctr.table()
+    # linearity: two half passes accumulate to the same table
+    S._ffi.check(wl.abi.sgc_sample_reset(wl.sample))
+    for first, m in ((0, 1_234_567), (1_234_567, n - 1_234_567)):
+        S._ffi.check(wl.abi.sgc_sample_push_packed(wl.sample, wl.records.data_ptr() + 8 * first, m, S._ffi.MEM_DEVICE))
+    S._ffi.check(wl.abi.sgc_sample_export_device(wl.sample, wl.export.data_ptr()))
+    c2, t2, m2 = wl.result()
+    assert (c2.tolist(), t2, m2) == (counts.tolist(), total, matched)
+    wl.close()
