@@ -72,7 +72,9 @@ typedef struct {
 int sgc_init(int device, sgc_ctx **out);
 void sgc_free(sgc_ctx *);
 
-/* Run everything on a caller-supplied hipStream_t instead of the ctx's own (NULL restores it). */
+/* Run everything on a caller-supplied hipStream_t instead of the ctx's own.  A NULL stream is the HIP
+ * legacy default stream, exactly as hipStream_t 0 is; SGC_STREAM_OWN returns to the ctx's own stream. */
+#define SGC_STREAM_OWN ((void *)(intptr_t)-1)
 int sgc_set_stream(sgc_ctx *, void *hip_stream);
 void *sgc_get_stream(sgc_ctx *);
 

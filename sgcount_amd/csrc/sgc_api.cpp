@@ -200,7 +200,7 @@ int sgc_set_stream(sgc_ctx *c, void *hip_stream) {
     if (!c) return fail(SGC_E_ARG, "sgc_set_stream: ctx is NULL");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->stream = hip_stream == SGC_STREAM_OWN ? c->own_stream : (hipStream_t)hip_stream;
     return SGC_OK;
 }
 
