@@ -53,6 +53,8 @@ typedef struct {
     double   lookup_ms;      /* Σ duration of the lookup/count kernel(s) */
     double   hist_ms;        /* Σ duration of the histogram kernel(s), 0 if fused */
     double   pack_ms;        /* Σ duration of the on-device pack kernel(s) */
+    double   part_ms;        /* Σ duration of the partition kernel (partitioned path) */
+    double   miss_ms;        /* Σ duration of the miss-resolution kernel (partitioned path) */
 } sgc_timing;
 
 typedef struct {

@@ -20,7 +20,7 @@ class SgcError(RuntimeError):
 
 class Timing(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("lookup_ms", C.c_double), ("hist_ms", C.c_double),
-                ("pack_ms", C.c_double)]
+                ("pack_ms", C.c_double), ("part_ms", C.c_double), ("miss_ms", C.c_double)]
 
 
 class LibInfo(C.Structure):

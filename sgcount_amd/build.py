@@ -18,8 +18,8 @@ SO = os.path.join(PKG, "libsgcount_hip.so")
 SYNTH_SO = os.path.join(PKG, "libsgcount_synth.so")
 
 TARGETS = {
-    SO: (["sgc_api.cpp", "sgc_tables.cpp", "sgc_kernels.hip"],
-         ["sgc_format.h", "sgc_kernels.h", "sgc_tables.h", os.path.join(INC, "sgcount_hip.h")]),
+    SO: (["sgc_api.cpp", "sgc_tables.cpp", "sgc_kernels.hip", "sgc_part.hip"],
+         ["sgc_format.h", "sgc_device.h", "sgc_kernels.h", "sgc_tables.h", os.path.join(INC, "sgcount_hip.h")]),
     SYNTH_SO: (["sgc_synth.hip"], ["sgc_format.h", "sgc_synth.h", os.path.join(INC, "sgcount_synth.h")]),
 }
 

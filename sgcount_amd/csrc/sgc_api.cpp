@@ -30,7 +30,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
                         std::string(#expr) + ": " + hipGetErrorString(e_));                    \
     } while (0)
 
-enum { T_LOOKUP = 0, T_HIST = 1, T_PACK = 2, T_KINDS = 3 };
+enum { T_LOOKUP = 0, T_HIST = 1, T_PACK = 2, T_PART = 3, T_MISS = 4, T_KINDS = 5 };
 
 struct sgc_ctx {
     int device = 0;
@@ -46,8 +46,14 @@ struct sgc_ctx {
     void *d_stage = nullptr; size_t stage_cap = 0;      // host -> device staging of pushed buffers
     void *d_aux = nullptr; size_t aux_cap = 0;          // offsets / secondary staging
     uint64_t *d_recs = nullptr; size_t recs_cap = 0;    // records produced by the on-device packers
+    void *d_gids = nullptr; size_t gids_cap = 0;        // per-read guide ids between the lookup and histogram kernels
+    void *d_pool = nullptr; size_t pool_cap = 0;        // partitioned path: record blocks
+    void *d_desc = nullptr; size_t desc_cap = 0;        // partitioned path: block descriptors
     // options
-    int variant = -1;           // count kernel variant; -1 = default
+    int variant = 3;            // count path variant: 0 direct atomics, 1/2 gid array + LDS histogram, 3 partitioned
+    int per_lane = 4;           // records per lane in the v2 lookup kernel
+    uint32_t dbg = 0;           // timing-only ablation flags (results are wrong when non-zero)
+    uint64_t max_chunk = 1ull << 27;   // records per internal pass (bounds the scratch buffers)
     // timing
     bool timing = false;
     struct span_ev { hipEvent_t a, b; int kind; };
@@ -90,6 +96,8 @@ static void timing_drain(sgc_ctx *c) {
         if (hipEventSynchronize(s.b) == hipSuccess && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
             if (s.kind == T_LOOKUP) c->acc.lookup_ms += ms;
             else if (s.kind == T_HIST) c->acc.hist_ms += ms;
+            else if (s.kind == T_PART) c->acc.part_ms += ms;
+            else if (s.kind == T_MISS) c->acc.miss_ms += ms;
             else c->acc.pack_ms += ms;
             c->acc.launches++;
         }
@@ -123,12 +131,47 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
     }
     uint64_t done = 0;
     while (done < n) {
-        const uint64_t chunk = std::min<uint64_t>(n - done, 0xF0000000ull);
+        const uint64_t chunk = std::min<uint64_t>(n - done, c->max_chunk);
         const uint64_t *p = d_recs + done * (c->rec16 ? 2 : 1);
-        {
+        if (c->variant >= 3 && sgc_part_supported(c->v_lib, c->rec16)) {
+            sgc_part_geometry g;
+            sgc_part_plan(chunk, c->v_lib, &g);
+            int rc = ensure(&c->d_pool, &c->pool_cap, g.pool_bytes);
+            if (rc) return rc;
+            rc = ensure(&c->d_desc, &c->desc_cap, g.desc_bytes);
+            if (rc) return rc;
+            uint64_t *pool = (uint64_t *)c->d_pool;
+            uint32_t *desc = (uint32_t *)c->d_desc;
+            { timed t(c, T_PART); sgc_launch_part_k1(c->stream, p, chunk, c->L, c->v_lib, g, pool, desc); }
+            { timed t(c, T_LOOKUP); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg); }
+            rc = ensure(&c->d_gids, &c->gids_cap, g.gids_bytes);                // one slot per pool record: every read may miss
+            if (rc) return rc;
+            rc = ensure(&c->d_aux, &c->aux_cap, ((size_t)g.n_segs + 1) * 4);
+            if (rc) return rc;
+            { timed t(c, T_MISS); sgc_launch_part_k3(c->stream, c->L, c->v_lib, c->v_perm, c->one_mm, g, pool, desc,
+                                                     (uint32_t *)c->d_aux, (uint32_t *)c->d_gids); }
+            { timed t(c, T_HIST); sgc_launch_part_k4(c->stream, c->n, g, (const uint32_t *)c->d_gids,
+                                                     (const uint32_t *)c->d_aux, s->d_c32, s->d_matched); }
+        } else if (c->variant == 0) {
             timed t(c, T_LOOKUP);
             sgc_launch_count_direct(c->stream, p, chunk, c->L, c->rec16, c->v_lib, c->v_perm, c->one_mm, s->d_c32,
                                     s->d_matched);
+        } else {
+            int rc = ensure(&c->d_gids, &c->gids_cap, (size_t)chunk * 4);
+            if (rc) return rc;
+            {
+                timed t(c, T_LOOKUP);
+                if (c->variant >= 2 && !c->rec16 && c->v_lib.gid_bits != 0)
+                    sgc_launch_lookup_gids_v2(c->stream, p, chunk, c->L, c->v_lib, c->v_perm, c->one_mm, c->per_lane,
+                                              (uint32_t *)c->d_gids, s->d_matched);
+                else
+                    sgc_launch_lookup_gids(c->stream, p, chunk, c->L, c->rec16, c->v_lib, c->v_perm, c->one_mm,
+                                           (uint32_t *)c->d_gids, s->d_matched);
+            }
+            {
+                timed t(c, T_HIST);
+                sgc_launch_hist_slices(c->stream, (const uint32_t *)c->d_gids, chunk, c->n, s->d_c32);
+            }
         }
         HIP_TRY(hipGetLastError());
         done += chunk;
@@ -192,6 +235,9 @@ void sgc_free(sgc_ctx *c) {
     if (c->d_stage) hipFree(c->d_stage);
     if (c->d_aux) hipFree(c->d_aux);
     if (c->d_recs) hipFree(c->d_recs);
+    if (c->d_gids) hipFree(c->d_gids);
+    if (c->d_pool) hipFree(c->d_pool);
+    if (c->d_desc) hipFree(c->d_desc);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -209,6 +255,15 @@ void *sgc_get_stream(sgc_ctx *c) { return c ? (void *)c->stream : nullptr; }
 int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
     if (!c || !key) return fail(SGC_E_ARG, "sgc_set_option: NULL argument");
     if (!strcmp(key, "variant")) { c->variant = (int)value; return SGC_OK; }
+    if (!strcmp(key, "dbg")) { c->dbg = (uint32_t)value; return SGC_OK; }
+    if (!strcmp(key, "max_chunk")) {
+        if (value < 1 || value > (int64_t)0xF0000000ll) return fail(SGC_E_ARG, "max_chunk out of range");
+        c->max_chunk = (uint64_t)value; return SGC_OK;
+    }
+    if (!strcmp(key, "per_lane")) {
+        if (value != 1 && value != 2 && value != 4) return fail(SGC_E_ARG, "per_lane must be 1, 2 or 4");
+        c->per_lane = (int)value; return SGC_OK;
+    }
     return fail(SGC_E_ARG, std::string("sgc_set_option: unknown key ") + key);
 }
 
@@ -223,6 +278,7 @@ static int upload_table(const sgc_host_table &h, uint64_t **d_slots, uint32_t **
     }
     HIP_TRY(hipStreamSynchronize(st));
     v->slots = *d_slots; v->vals = *d_vals; v->log2_slots = h.log2_slots; v->gid_bits = h.gid_bits;
+    v->log2_slice = h.log2_slice; v->pad_ = 0;
     return SGC_OK;
 }
 
@@ -234,11 +290,11 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
     std::vector<uint64_t> keys;
     sgc_host_table h_lib, h_perm;
     std::string err;
-    int rc = sgc_build_library_table(seqs, n, L, keys, h_lib, err);
+    int rc = sgc_build_library_table(seqs, n, L, SGC_LDS_LOG2_SLICE, keys, h_lib, err);
     if (rc != SGC_OK) return fail(rc, "sgc_set_library: " + err);
     rc = upload_table(h_lib, &c->d_lib_slots, &c->d_lib_vals, &c->v_lib, c->stream);
     if (rc != SGC_OK) { free_tables(c); return rc; }
-    c->v_perm = sgc_table_view{nullptr, nullptr, 0, h_lib.gid_bits};
+    c->v_perm = sgc_table_view{nullptr, nullptr, 0, h_lib.gid_bits, 0, 0};
     c->perm_entries = 0;
     if (enable_1mm) {
         sgc_build_permute_table(keys, L, h_lib, h_perm);

@@ -1,0 +1,107 @@
+// sgc_device.h — device-side helpers shared by the gfx950 kernels: table probes and the restatement of
+// Counter::assign (reference src/counter.rs:96-140).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sgc_format.h"
+
+// ------------------------------------------------------------------------------------------------
+// bucketised open addressing: one 16-byte load reads both slots of a bucket
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ ulonglong2 load_bucket(const sgc_table_view &t, uint32_t b) {
+    return reinterpret_cast<const ulonglong2 *>(t.slots)[b];
+}
+
+// 0 = keep probing, 1 = resolved (g holds the guide id or SGC_NONE); packed layout
+__device__ __forceinline__ bool bucket_resolve(const ulonglong2 &v, uint64_t key, uint32_t gid_bits, uint32_t &g) {
+    const uint64_t gmask = (1ull << gid_bits) - 1ull;
+    if ((v.x >> gid_bits) == key && v.x != SGC_EMPTY) { g = (uint32_t)(v.x & gmask); return true; }
+    if (v.x == SGC_EMPTY) { g = SGC_NONE; return true; }
+    if ((v.y >> gid_bits) == key && v.y != SGC_EMPTY) { g = (uint32_t)(v.y & gmask); return true; }
+    if (v.y == SGC_EMPTY) { g = SGC_NONE; return true; }
+    return false;
+}
+
+template <bool PACKED>
+__device__ __forceinline__ uint32_t table_find(const sgc_table_view &t, uint64_t key) {
+    uint32_t b = sgc_home_bucket(key, t.log2_slots);
+    for (;;) {
+        const ulonglong2 v = load_bucket(t, b);
+        if (PACKED) {
+            uint32_t g;
+            if (bucket_resolve(v, key, t.gid_bits, g)) return g;
+        } else {
+            if (v.x == SGC_EMPTY) return SGC_NONE;
+            if (v.x == key) return t.vals[2 * b];
+            if (v.y == SGC_EMPTY) return SGC_NONE;
+            if (v.y == key) return t.vals[2 * b + 1];
+        }
+        b = sgc_next_bucket(b, t.log2_slice);
+    }
+}
+
+// continue a probe whose home bucket `v` (index b) has already been loaded (packed layout)
+__device__ __forceinline__ uint32_t finish_find(const sgc_table_view &t, uint64_t key, uint32_t b, ulonglong2 v) {
+    for (;;) {
+        uint32_t g;
+        if (bucket_resolve(v, key, t.gid_bits, g)) return g;
+        b = sgc_next_bucket(b, t.log2_slice);
+        v = load_bucket(t, b);
+    }
+}
+__device__ __forceinline__ uint32_t bucket_of(const sgc_table_view &t, uint64_t key) {
+    return sgc_home_bucket(key, t.log2_slots);
+}
+
+// One window: exact, then single mismatch.  state: 0 clean, 1 dead, 2+j single 'N' at j.
+template <bool PACKED>
+__device__ __forceinline__ uint32_t window_assign(uint64_t key, uint32_t state, const sgc_table_view &lib,
+                                                  const sgc_table_view &perm, bool one_mm) {
+    if (state == SGC_STATE_CLEAN) {
+        uint32_t g = table_find<PACKED>(lib, key);                 // src/counter.rs:111
+        if (g == SGC_NONE && one_mm) g = table_find<PACKED>(perm, key);   // :113-116 (child -> parent -> alias)
+        return g;
+    }
+    if (state == SGC_STATE_DEAD || !one_mm) return SGC_NONE;
+    // exactly one 'N' at position j: the Hamming-1 guides are the (up to 4) substitutions at j;
+    // src/permutes.rs:127-144 keeps the child only if its parent is unique.
+    const uint32_t j = state - 2u;
+    uint32_t hit = SGC_NONE, cnt = 0;
+#pragma unroll
+    for (uint64_t b = 0; b < 4; b++) {
+        const uint32_t g = table_find<PACKED>(lib, key | (b << (2 * j)));
+        if (g != SGC_NONE) { hit = g; cnt++; }
+    }
+    return cnt == 1 ? hit : SGC_NONE;
+}
+
+template <bool PACKED>
+__device__ __forceinline__ uint32_t sgc_assign(uint64_t span, uint64_t status, uint32_t L, const sgc_table_view &lib,
+                                               const sgc_table_view &perm, bool one_mm) {
+    const uint64_t kmask = sgc_key_mask(L);
+    uint32_t sC = 0, sP = 0, sM = 0;
+    if (status != 0) {
+        const uint32_t K = L + 2, st = (uint32_t)status;
+        sC = st % K; sP = (st / K) % K; sM = st / (K * K);
+    }
+    uint32_t g = window_assign<PACKED>((span >> 2) & kmask, sC, lib, perm, one_mm);        // Centered
+    if (g != SGC_NONE) return g;
+    g = window_assign<PACKED>((span >> 4) & kmask, sP, lib, perm, one_mm);                  // Plus  (:123-125)
+    if (g != SGC_NONE) return g;
+    return window_assign<PACKED>(span & kmask, sM, lib, perm, one_mm);                      // Minus (:128-130)
+}
+
+template <bool REC16>
+__device__ __forceinline__ void load_record(const uint64_t *recs, uint64_t i, uint32_t L, uint64_t &span,
+                                            uint64_t &status) {
+    if (REC16) {
+        const ulonglong2 r = reinterpret_cast<const ulonglong2 *>(recs)[i];
+        span = r.x; status = r.y;
+    } else {
+        const uint64_t r = recs[i];
+        const uint32_t sh = 2 * (L + 2);
+        span = r & ((1ull << sh) - 1ull);     // sh <= 50
+        status = r >> sh;
+    }
+}

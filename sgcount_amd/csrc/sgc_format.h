@@ -61,12 +61,30 @@ SGC_HD uint64_t sgc_hash(uint64_t key) {
     return key * 0x9E3779B97F4A7C15ull;
 }
 
+// Open-addressed table of 2-slot BUCKETS (16 bytes, read with one 16-byte load).  A key's home bucket is
+// the top (log2_slots - 1) bits of its hash; an insert scans buckets from there and takes the first free
+// slot, so a lookup scans the same buckets and stops at the first match or the first free slot.  The slot
+// array is cut into 2^(log2_slots - log2_slice) *slices*; probing wraps INSIDE the home slice, so a slice
+// is a self-contained hash table (the partitioned count path stages one slice per workgroup in LDS, the
+// global paths probe the very same array).  An unpartitioned table has log2_slice == log2_slots.
 struct sgc_table_view {
     const uint64_t *slots;   // packed: (key << gid_bits) | gid, SGC_EMPTY if free; split: key or SGC_EMPTY
     const uint32_t *vals;    // split layout only: gid per slot
     uint32_t log2_slots;
     uint32_t gid_bits;       // 0 => split layout
+    uint32_t log2_slice;
+    uint32_t pad_;
 };
+
+SGC_HD uint32_t sgc_home_bucket(uint64_t key, uint32_t log2_slots) { return (uint32_t)(sgc_hash(key) >> (65 - log2_slots)); }
+SGC_HD uint32_t sgc_next_bucket(uint32_t b, uint32_t log2_slice) {
+    const uint32_t m = (1u << (log2_slice - 1)) - 1u;
+    return (b & ~m) | ((b + 1) & m);
+}
+// slice (= partition of the partitioned count path) a key belongs to
+SGC_HD uint32_t sgc_slice_of(uint64_t key, uint32_t log2_slots, uint32_t log2_slice) {
+    return sgc_home_bucket(key, log2_slots) >> (log2_slice - 1);
+}
 
 // Builds one record from a read.  `emit(span_bits, status)` style is avoided to keep this usable in
 // kernels: returns span and status through references.

@@ -5,6 +5,10 @@
 
 #include "sgc_format.h"
 
+// slots per library-table slice staged in LDS by the partitioned path: 2^12 x 8 B = 32 KiB of keys plus
+// 16 KiB of counters, so that two 1024-lane workgroups share a CU's 160 KiB
+#define SGC_LDS_LOG2_SLICE 12u
+
 void sgc_launch_count_direct(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, bool rec16,
                              const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm, uint32_t *counts,
                              unsigned long long *matched);
@@ -13,3 +17,27 @@ void sgc_launch_lookup(hipStream_t st, const uint64_t *keys, uint64_t n, const s
 void sgc_launch_fold(hipStream_t st, uint32_t *c32, unsigned long long *c64, uint32_t n);
 void sgc_launch_pack_reads(hipStream_t st, const uint8_t *seqs, const uint64_t *offsets, uint64_t n, uint32_t L,
                            bool rec16, int reverse, uint32_t o, int recursion, uint64_t *recs);
+void sgc_launch_lookup_gids(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, bool rec16,
+                            const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm, uint32_t *gids,
+                            unsigned long long *matched);
+void sgc_launch_hist_slices(hipStream_t st, const uint32_t *gids, uint64_t n, uint32_t n_guides, uint32_t *counts);
+void sgc_launch_lookup_gids_v2(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L,
+                               const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm, int per_lane,
+                               uint32_t *gids, unsigned long long *matched);
+
+// ---- partitioned count path (sgc_part.hip) ------------------------------------------------------
+struct sgc_part_geometry {
+    uint32_t k1_wgs, blocks_per_wg, n_blocks, partitions, n_segs;
+    uint64_t per_wg, pool_bytes, desc_bytes, gids_bytes;
+};
+bool sgc_part_supported(const sgc_table_view &lib, bool rec16);
+void sgc_part_plan(uint64_t n, const sgc_table_view &lib, sgc_part_geometry *g);
+void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib,
+                        const sgc_part_geometry &g, uint64_t *pool, uint32_t *desc);
+void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_part_geometry &g,
+                        uint64_t *pool, uint32_t *desc, uint32_t *counts, unsigned long long *matched, uint32_t dbg);
+void sgc_launch_part_k3(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm,
+                        const sgc_part_geometry &g, const uint64_t *pool, const uint32_t *desc, uint32_t *seg_cnt,
+                        uint32_t *gids);
+void sgc_launch_part_k4(hipStream_t st, uint32_t n_guides, const sgc_part_geometry &g, const uint32_t *gids,
+                        const uint32_t *seg_cnt, uint32_t *counts, unsigned long long *matched);

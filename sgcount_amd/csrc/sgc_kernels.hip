@@ -9,79 +9,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "sgc_device.h"
 #include "sgc_format.h"
 #include "sgc_kernels.h"
-
-// ------------------------------------------------------------------------------------------------
-// open-addressed lookup (linear probing; load factor <= 0.5 so a free slot always ends the chain)
-// ------------------------------------------------------------------------------------------------
-template <bool PACKED>
-__device__ __forceinline__ uint32_t table_find(const sgc_table_view &t, uint64_t key) {
-    const uint32_t mask = (1u << t.log2_slots) - 1u;
-    uint32_t h = (uint32_t)(sgc_hash(key) >> (64 - t.log2_slots));
-    for (;;) {
-        const uint64_t s = t.slots[h];
-        if (s == SGC_EMPTY) return SGC_NONE;
-        if (PACKED) {
-            if ((s >> t.gid_bits) == key) return (uint32_t)(s & ((1ull << t.gid_bits) - 1ull));
-        } else {
-            if (s == key) return t.vals[h];
-        }
-        h = (h + 1) & mask;
-    }
-}
-
-// One window: exact, then single mismatch.  state: 0 clean, 1 dead, 2+j single 'N' at j.
-template <bool PACKED>
-__device__ __forceinline__ uint32_t window_assign(uint64_t key, uint32_t state, const sgc_table_view &lib,
-                                                  const sgc_table_view &perm, bool one_mm) {
-    if (state == SGC_STATE_CLEAN) {
-        uint32_t g = table_find<PACKED>(lib, key);                 // src/counter.rs:111
-        if (g == SGC_NONE && one_mm) g = table_find<PACKED>(perm, key);   // :113-116 (child -> parent -> alias)
-        return g;
-    }
-    if (state == SGC_STATE_DEAD || !one_mm) return SGC_NONE;
-    // exactly one 'N' at position j: the Hamming-1 guides are the (up to 4) substitutions at j;
-    // src/permutes.rs:127-144 keeps the child only if its parent is unique.
-    const uint32_t j = state - 2u;
-    uint32_t hit = SGC_NONE, cnt = 0;
-#pragma unroll
-    for (uint64_t b = 0; b < 4; b++) {
-        const uint32_t g = table_find<PACKED>(lib, key | (b << (2 * j)));
-        if (g != SGC_NONE) { hit = g; cnt++; }
-    }
-    return cnt == 1 ? hit : SGC_NONE;
-}
-
-template <bool PACKED>
-__device__ __forceinline__ uint32_t sgc_assign(uint64_t span, uint64_t status, uint32_t L, const sgc_table_view &lib,
-                                               const sgc_table_view &perm, bool one_mm) {
-    const uint64_t kmask = sgc_key_mask(L);
-    uint32_t sC = 0, sP = 0, sM = 0;
-    if (status != 0) {
-        const uint32_t K = L + 2, st = (uint32_t)status;
-        sC = st % K; sP = (st / K) % K; sM = st / (K * K);
-    }
-    uint32_t g = window_assign<PACKED>((span >> 2) & kmask, sC, lib, perm, one_mm);        // Centered
-    if (g != SGC_NONE) return g;
-    g = window_assign<PACKED>((span >> 4) & kmask, sP, lib, perm, one_mm);                  // Plus  (:123-125)
-    if (g != SGC_NONE) return g;
-    return window_assign<PACKED>(span & kmask, sM, lib, perm, one_mm);                      // Minus (:128-130)
-}
-
-template <bool REC16>
-__device__ __forceinline__ void load_record(const uint64_t *recs, uint64_t i, uint32_t L, uint64_t &span,
-                                            uint64_t &status) {
-    if (REC16) {
-        const ulonglong2 r = reinterpret_cast<const ulonglong2 *>(recs)[i];
-        span = r.x; status = r.y;
-    } else {
-        const uint64_t r = recs[i];
-        const uint32_t sh = 2 * (L + 2);
-        span = r & ((1ull << sh) - 1ull);     // sh <= 50
-        status = r >> sh;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // v0 count kernel: one record per thread (grid-stride), device-scope atomics on the count vector.
@@ -102,6 +32,125 @@ __global__ void __launch_bounds__(256) k_count_direct(const uint64_t *__restrict
     // wave reduction of the matched tally, one atomic per wave
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(matched, (unsigned long long)local);
+}
+
+// ------------------------------------------------------------------------------------------------
+// variant 1: lookup kernel writes one gid per read (coalesced u32 stores, no count atomics); a second
+// kernel builds the histogram in LDS, one guide-range slice per pass, and flushes each slice with
+// contiguous (256 B per wave-instruction) device-scope atomics.  Scattered device-scope atomics run at
+// ~20 G requests/s chip-wide on MI355X (they execute at the memory side), LDS atomics do not.
+// ------------------------------------------------------------------------------------------------
+template <bool PACKED, bool REC16>
+__global__ void __launch_bounds__(256) k_lookup_gids(const uint64_t *__restrict__ recs, uint64_t n, uint32_t L,
+                                                     sgc_table_view lib, sgc_table_view perm, int one_mm,
+                                                     uint32_t *__restrict__ gids,
+                                                     unsigned long long *__restrict__ matched) {
+    uint64_t local = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t span, status;
+        load_record<REC16>(recs, i, L, span, status);
+        const uint32_t g = sgc_assign<PACKED>(span, status, L, lib, perm, one_mm != 0);
+        gids[i] = g;
+        local += g != SGC_NONE;
+    }
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(matched, (unsigned long long)local);
+}
+
+// ------------------------------------------------------------------------------------------------
+// variant 2 lookup: R records per lane and speculative probing.
+//   phase A  every lane probes the library with the Centered key of its R records (R independent
+//            gathers in flight per lane instead of one);
+//   phase B  a record that missed issues both remaining library probes (Plus, Minus: cheap, L2) at once
+//            and walks the permute probes (Infinity Cache: ~5x dearer per gather) only as far as the
+//            reference's priority order needs them (src/counter.rs:111-135).
+//   Records with a non-zero status (an 'N', a dead window, a short read: ~2 % of reads) take the
+//   generic sequential path.  rec8 + packed tables only; other layouts use k_lookup_gids.
+// Streaming traffic (records in, gids out) is non-temporal so that it does not evict the 2 MB library
+// table from the XCD's L2.
+// ------------------------------------------------------------------------------------------------
+template <bool ONE_MM, int R>
+__global__ void __launch_bounds__(256) k_lookup_gids_v2(const uint64_t *__restrict__ recs, uint64_t n, uint32_t L,
+                                                        sgc_table_view lib, sgc_table_view perm,
+                                                        uint32_t *__restrict__ gids,
+                                                        unsigned long long *__restrict__ matched) {
+    const uint32_t sh = 2 * (L + 2);
+    const uint64_t smask = (1ull << sh) - 1ull, kmask = sgc_key_mask(L);
+    uint64_t local = 0;
+    const uint64_t n_groups = n / R;
+    for (uint64_t grp = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; grp < n_groups;
+         grp += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t rec[R], keyC[R];
+        ulonglong2 sl[R];
+        uint32_t hC[R], g[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) rec[r] = __builtin_nontemporal_load(&recs[grp * R + r]);
+        // phase A
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            keyC[r] = (rec[r] >> 2) & kmask;
+            hC[r] = bucket_of(lib, keyC[r]);
+            sl[r] = load_bucket(lib, hC[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if ((rec[r] >> sh) != 0) g[r] = sgc_assign<true>(rec[r] & smask, rec[r] >> sh, L, lib, perm, ONE_MM);
+            else g[r] = finish_find(lib, keyC[r], hC[r], sl[r]);
+        }
+        // phase B
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (g[r] != SGC_NONE || (rec[r] >> sh) != 0) continue;
+            const uint64_t keyP = (rec[r] >> 4) & kmask, keyM = rec[r] & kmask;
+            const uint32_t hP = bucket_of(lib, keyP), hM = bucket_of(lib, keyM);
+            const ulonglong2 a1 = load_bucket(lib, hP), a3 = load_bucket(lib, hM);
+            uint32_t x = SGC_NONE;
+            if (ONE_MM) x = table_find<true>(perm, keyC[r]);
+            if (x == SGC_NONE) x = finish_find(lib, keyP, hP, a1);
+            if (ONE_MM && x == SGC_NONE) x = table_find<true>(perm, keyP);
+            if (x == SGC_NONE) x = finish_find(lib, keyM, hM, a3);
+            if (ONE_MM && x == SGC_NONE) x = table_find<true>(perm, keyM);
+            g[r] = x;
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            __builtin_nontemporal_store(g[r], &gids[grp * R + r]);
+            local += g[r] != SGC_NONE;
+        }
+    }
+    // tail (n % R records), one lane each
+    const uint64_t tail0 = n_groups * R, t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n - tail0) {
+        const uint64_t rec = recs[tail0 + t];
+        const uint32_t x = sgc_assign<true>(rec & smask, rec >> sh, L, lib, perm, ONE_MM);
+        gids[tail0 + t] = x;
+        local += x != SGC_NONE;
+    }
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(matched, (unsigned long long)local);
+}
+
+#define SGC_HIST_SLICE 36864u   // u32 counters per LDS slice (144 KiB of the CU's 160 KiB)
+__global__ void __launch_bounds__(1024) k_hist_slices(const uint32_t *__restrict__ gids, uint64_t n, uint32_t n_guides,
+                                                      uint32_t *__restrict__ counts) {
+    __shared__ uint32_t h[SGC_HIST_SLICE];
+    const uint64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const uint64_t lo = (uint64_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (uint32_t base = 0; base < n_guides; base += SGC_HIST_SLICE) {
+        for (uint32_t j = threadIdx.x; j < SGC_HIST_SLICE; j += 1024) h[j] = 0;
+        __syncthreads();
+        for (uint64_t i = lo + threadIdx.x; i < hi; i += 1024) {
+            const uint32_t r = gids[i] - base;
+            if (r < SGC_HIST_SLICE) atomicAdd(&h[r], 1u);
+        }
+        __syncthreads();
+        const uint32_t lim = n_guides - base < SGC_HIST_SLICE ? n_guides - base : SGC_HIST_SLICE;
+        for (uint32_t j = threadIdx.x; j < lim; j += 1024) {
+            const uint32_t v = h[j];
+            if (v) atomicAdd(&counts[base + j], v);
+        }
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -163,6 +212,38 @@ void sgc_launch_count_direct(hipStream_t st, const uint64_t *recs, uint64_t n, u
     if (packed) { if (rec16) SGC_GO(true, true); else SGC_GO(true, false); }
     else        { if (rec16) SGC_GO(false, true); else SGC_GO(false, false); }
 #undef SGC_GO
+}
+
+void sgc_launch_lookup_gids(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, bool rec16,
+                            const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm, uint32_t *gids,
+                            unsigned long long *matched) {
+    if (n == 0) return;
+    const unsigned block = 256, grid = grid_for(n, block, 256 * 8 * 4);
+    const bool packed = lib.gid_bits != 0;
+#define SGC_GO(P, R) \
+    hipLaunchKernelGGL((k_lookup_gids<P, R>), dim3(grid), dim3(block), 0, st, recs, n, L, lib, perm, (int)one_mm, gids, matched)
+    if (packed) { if (rec16) SGC_GO(true, true); else SGC_GO(true, false); }
+    else        { if (rec16) SGC_GO(false, true); else SGC_GO(false, false); }
+#undef SGC_GO
+}
+
+void sgc_launch_lookup_gids_v2(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L,
+                               const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm, int per_lane,
+                               uint32_t *gids, unsigned long long *matched) {
+    if (n == 0) return;
+    const unsigned block = 256;
+    const uint64_t groups = (n + per_lane - 1) / per_lane;
+    const unsigned grid = grid_for(groups, block, 256 * 8 * 2);
+#define SGC_GO(M, R) \
+    hipLaunchKernelGGL((k_lookup_gids_v2<M, R>), dim3(grid), dim3(block), 0, st, recs, n, L, lib, perm, gids, matched)
+    if (one_mm) { if (per_lane == 4) SGC_GO(true, 4); else if (per_lane == 2) SGC_GO(true, 2); else SGC_GO(true, 1); }
+    else        { if (per_lane == 4) SGC_GO(false, 4); else if (per_lane == 2) SGC_GO(false, 2); else SGC_GO(false, 1); }
+#undef SGC_GO
+}
+
+void sgc_launch_hist_slices(hipStream_t st, const uint32_t *gids, uint64_t n, uint32_t n_guides, uint32_t *counts) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_hist_slices, dim3(256), dim3(1024), 0, st, gids, n, n_guides, counts);
 }
 
 void sgc_launch_lookup(hipStream_t st, const uint64_t *keys, uint64_t n, const sgc_table_view &lib,

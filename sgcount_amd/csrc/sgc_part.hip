@@ -1,0 +1,449 @@
+// sgc_part.hip — the partitioned count path (variant 3), gfx950.
+//
+// Why: a random 8-byte gather served by the XCD L2 runs at ~0.26 T gathers/s chip-wide on MI355X and one
+// served by the Infinity Cache at ~0.055 T/s (tools/ubench/gather.hip), and scattered device-scope atomics
+// at ~0.02 T/s — while an LDS gather/atomic is an order of magnitude cheaper than any of them.  So the
+// reads are first radix-partitioned by the hash of their Centered key; a workgroup then stages ONE slice of
+// the library table (<= 64 KiB) in LDS and resolves and counts its partition there.  Only the reads that
+// miss (Plus/Minus windows, single mismatch, 'N') — ~15 % of the synthetic mix — go on to global probes.
+//
+//   K1 k_partition     records -> blocks of B records, one partition per block.  Atomic-free: workgroup w
+//                      owns the block range [w*M, (w+1)*M) and hands blocks to partitions as they fill; a
+//                      descriptor per block records (partition, fill).  LDS stages each tile so that the
+//                      global writes are contiguous runs.
+//   K2 k_count_slices  workgroup (p, g): slice p of the library table -> LDS, per-slot LDS counters; every
+//                      block of partition p: Centered-exact probe in LDS (Counter::assign's first and by far
+//                      most frequent outcome, src/counter.rs:111); hits count in LDS, misses are compacted IN
+//                      PLACE to the front of the block (descriptor fill := number of misses).  At the end the
+//                      slot counters are flushed with one device-scope atomic per occupied slot.
+//   K3 k_resolve_miss  the rest of the chain for the compacted misses (src/counter.rs:113-135) with global
+//                      probes; the guide id replaces the record in place.
+//   K4 k_hist_blocks   LDS histogram of those guide ids, slice by slice (as k_hist_slices).
+//
+// rec8 records and packed table slots only; other layouts use the generic kernels.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sgc_device.h"
+#include "sgc_format.h"
+#include "sgc_kernels.h"
+
+#define PART_TILE 2048u          // records staged per tile in K1 (== block size)
+#define PART_BLOCK 2048u         // records per block
+#define PART_MAXP 64u            // max partitions (library slices)
+#define DESC_FILL_MASK 0xFFFFu
+
+static_assert(PART_TILE <= PART_BLOCK, "a tile must fit one block");
+
+__device__ __forceinline__ uint32_t part_of(uint64_t rec, uint64_t kmask, uint32_t log2_slots, uint32_t log2_slice) {
+    return sgc_slice_of((rec >> 2) & kmask, log2_slots, log2_slice);
+}
+
+// ------------------------------------------------------------------------------------------------ K1
+__global__ void __launch_bounds__(256) k_partition(const uint64_t *__restrict__ recs, uint64_t n, uint64_t per_wg,
+                                                   uint32_t blocks_per_wg, uint32_t L, uint32_t log2_slots,
+                                                   uint32_t log2_slice, uint64_t *__restrict__ pool,
+                                                   uint32_t *__restrict__ desc) {
+    __shared__ uint64_t stage[PART_TILE];
+    __shared__ uint32_t cnt[PART_MAXP], start[PART_MAXP], blk[PART_MAXP], fill[PART_MAXP];
+    __shared__ uint32_t dst_a[PART_MAXP], dst_b[PART_MAXP], split[PART_MAXP];
+    __shared__ uint32_t next_free;
+    const uint32_t P = 1u << (log2_slots - log2_slice), t = threadIdx.x;
+    const uint64_t kmask = sgc_key_mask(L);
+    const uint64_t lo = (uint64_t)blockIdx.x * per_wg;
+    const uint64_t hi = lo + per_wg < n ? lo + per_wg : n;
+    const uint32_t block0 = blockIdx.x * blocks_per_wg;
+    if (t < PART_MAXP) { blk[t] = 0xFFFFFFFFu; fill[t] = PART_BLOCK; }
+    if (t == 0) next_free = 0;
+    __syncthreads();
+    for (uint64_t base = lo; base < hi; base += PART_TILE) {
+        const uint32_t m = (uint32_t)(hi - base < PART_TILE ? hi - base : PART_TILE);
+        if (t < PART_MAXP) cnt[t] = 0;
+        __syncthreads();
+        uint64_t rec[PART_TILE / 256];
+        uint32_t pr[PART_TILE / 256];     // partition << 16 | rank inside the tile
+#pragma unroll
+        for (uint32_t k = 0; k < PART_TILE / 256; k++) {
+            const uint32_t j = k * 256 + t;
+            if (j < m) rec[k] = __builtin_nontemporal_load(&recs[base + j]);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < PART_TILE / 256; k++) {
+            const uint32_t j = k * 256 + t;
+            if (j < m) {
+                const uint32_t p = part_of(rec[k], kmask, log2_slots, log2_slice);
+                pr[k] = (p << 16) | atomicAdd(&cnt[p], 1u);
+            }
+        }
+        __syncthreads();
+        // one lane per partition: exclusive scan of the tile counts, and where the tile's run goes.  A run
+        // first tops up the partition's open block, the remainder opens a new one, so every closed block is
+        // full and a workgroup never needs more than per_wg / BLOCK + P blocks.
+        if (t < 64) {
+            const uint32_t c = t < P ? cnt[t] : 0;
+            uint32_t incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t v = __shfl_up(incl, off, 64);
+                if ((int)t >= off) incl += v;
+            }
+            if (t < P) {
+                start[t] = incl - c;
+                if (c) {
+                    const uint32_t room = PART_BLOCK - fill[t];          // 0 when no block is open
+                    const uint32_t head = c < room ? c : room;
+                    split[t] = head;
+                    dst_a[t] = head ? blk[t] * PART_BLOCK + fill[t] : 0;
+                    fill[t] += head;
+                    if (c > head) {
+                        if (blk[t] != 0xFFFFFFFFu) desc[blk[t]] = ((t + 1) << 16) | PART_BLOCK;    // close, full
+                        blk[t] = block0 + atomicAdd(&next_free, 1u);
+                        dst_b[t] = blk[t] * PART_BLOCK;
+                        fill[t] = c - head;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < PART_TILE / 256; k++) {
+            const uint32_t j = k * 256 + t;
+            if (j < m) stage[start[pr[k] >> 16] + (pr[k] & 0xFFFFu)] = rec[k];
+        }
+        __syncthreads();
+        for (uint32_t j = t; j < m; j += 256) {
+            const uint64_t r = stage[j];
+            const uint32_t p = part_of(r, kmask, log2_slots, log2_slice);
+            const uint32_t rank = j - start[p];
+            const uint64_t at = rank < split[p] ? (uint64_t)dst_a[p] + rank : (uint64_t)dst_b[p] + (rank - split[p]);
+            pool[at] = r;
+        }
+        __syncthreads();
+    }
+    if (t < P && blk[t] != 0xFFFFFFFFu) desc[blk[t]] = ((t + 1) << 16) | fill[t];
+}
+
+// ------------------------------------------------------------------------------------------------ K2
+#define K2_THREADS 1024u
+#define K2_LIST 2048u            // capacity of the per-round block list
+#define K2_U 4u                  // blocks per group: one group is processed while the next is in flight
+template <int LOG2_SLICE>
+__global__ void __launch_bounds__(K2_THREADS) k_count_slices(uint64_t *__restrict__ pool, uint32_t *__restrict__ desc,
+                                                             uint32_t n_blocks, uint32_t G, uint32_t L,
+                                                             sgc_table_view lib, uint32_t *__restrict__ counts,
+                                                             unsigned long long *__restrict__ matched, uint32_t dbg) {
+    constexpr uint32_t S = 1u << LOG2_SLICE;
+    constexpr uint32_t RPT = PART_BLOCK / K2_THREADS;       // records per thread per block
+    constexpr uint32_t Q = K2_U * RPT;                       // records per thread per group
+    __shared__ ulonglong2 tab[S / 2];                        // the slice, bucket by bucket
+    __shared__ uint32_t cnt[S];
+    __shared__ uint32_t list[K2_LIST];                       // block id << 11 | (fill - 1)
+    __shared__ uint32_t n_list, miss_cnt[2][K2_U];
+    const uint32_t t = threadIdx.x, p = blockIdx.x / G, g = blockIdx.x % G;
+    const uint32_t slice = lib.log2_slice < (uint32_t)LOG2_SLICE ? (1u << lib.log2_slice) : S;   // small libraries
+    const uint32_t bmask = slice / 2 - 1u, gid_bits = lib.gid_bits;
+    const uint32_t sh = 2 * (L + 2);
+    const uint64_t kmask = sgc_key_mask(L);
+    const ulonglong2 *gtab = reinterpret_cast<const ulonglong2 *>(lib.slots) + (uint64_t)p * (slice / 2);
+    for (uint32_t i = t; i < S / 2; i += K2_THREADS) {      // bare keys in LDS (a key is < 2^60, so SGC_EMPTY stays distinct)
+        ulonglong2 v = i < slice / 2 ? gtab[i] : make_ulonglong2(SGC_EMPTY, SGC_EMPTY);
+        if (v.x != SGC_EMPTY) v.x >>= gid_bits;
+        if (v.y != SGC_EMPTY) v.y >>= gid_bits;
+        tab[i] = v;
+    }
+    for (uint32_t i = t; i < S; i += K2_THREADS) cnt[i] = 0;
+    if (t < 2 * K2_U) miss_cnt[t / K2_U][t % K2_U] = 0;
+    // descriptors are scanned in windows; the blocks of partition p whose id hashes to g are listed, then
+    // processed (a plain id % G would hand one workgroup ALL blocks of a partition: K1 opens blocks for the
+    // partitions in a repeating order)
+    const uint32_t window = (K2_LIST / 2) * G;      // <= K2_LIST/2 expected matches per round even if every block is p's
+    for (uint32_t win = 0; win < n_blocks; win += window) {
+        if (t == 0) n_list = 0;
+        __syncthreads();
+        for (uint32_t k = t; k < window; k += K2_THREADS) {
+            const uint32_t b = win + k;
+            if (b < n_blocks && ((b * 0x9E3779B1u) >> 16) % G == g) {
+                const uint32_t d = desc[b];
+                if ((d >> 16) == p + 1 && (d & DESC_FILL_MASK)) {
+                    const uint32_t at = atomicAdd(&n_list, 1u);
+                    if (at < K2_LIST) list[at] = (b << 11) | ((d & DESC_FILL_MASK) - 1u);   // cannot overflow: tests/test_abi_cpu.py::test_k2_window_bound
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t nl = n_list < K2_LIST ? n_list : K2_LIST;
+        // software pipeline over groups of K2_U blocks: `cur` is processed while `nxt` is in flight
+        uint64_t cur[Q], nxt[Q];
+        uint32_t cur_valid = 0, nxt_valid = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < Q; q++) {
+            const uint32_t u = q / RPT, j = (q % RPT) * K2_THREADS + t;
+            const uint32_t e = u < nl ? list[u] : 0;
+            const bool ok = u < nl && j <= (e & 2047u);
+            cur[q] = ok ? pool[(uint64_t)(e >> 11) * PART_BLOCK + j] : 0;
+            if (ok) cur_valid |= 1u << q;
+        }
+        for (uint32_t li = 0; li < nl; li += K2_U) {
+            const uint32_t par = (li / K2_U) & 1u;
+            // all records of group li are in registers (this also publishes the previous group's miss counts)
+            __syncthreads();
+            if (t < K2_U) {
+                if (li) desc[list[li - K2_U + t] >> 11] = ((p + 1) << 16) | miss_cnt[par ^ 1u][t];
+                miss_cnt[par ^ 1u][t] = 0;
+            }
+            nxt_valid = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < Q; q++) {
+                const uint32_t u = li + K2_U + q / RPT, j = (q % RPT) * K2_THREADS + t;
+                const uint32_t e = u < nl ? list[u] : 0;
+                const bool ok = u < nl && j <= (e & 2047u);
+                nxt[q] = ok ? pool[(uint64_t)(e >> 11) * PART_BLOCK + j] : 0;
+                if (ok) nxt_valid |= 1u << q;
+            }
+            // Centered-exact probe (src/counter.rs:111) of the Q records against the slice in LDS.  The LDS copy
+            // holds bare keys, so a bucket resolves with four 64-bit compares and no branches (K2 is bound by
+            // instruction issue — one scalar unit per CU — not by memory); the rare longer chains are walked in
+            // a loop.  An insert fills slot 0 before slot 1, so "slot 1 free" means "chain ends here".
+#pragma unroll
+            for (uint32_t q = 0; q < Q; q++) {
+                const uint64_t key = (cur[q] >> 2) & kmask;
+                uint32_t b = sgc_home_bucket(key, lib.log2_slots) & bmask;
+                ulonglong2 w = tab[b];
+                const bool want = (cur_valid >> q & 1u) && (cur[q] >> sh) == 0 && !(dbg & 4);
+                bool hit = want && (w.x == key || w.y == key);
+                bool cont = want && !hit && w.y != SGC_EMPTY;
+                while (cont) {
+                    b = (b + 1) & bmask;
+                    w = tab[b];
+                    hit = w.x == key || w.y == key;
+                    cont = !hit && w.y != SGC_EMPTY && !(dbg & 8);
+                }
+                if (hit && !(dbg & 1)) atomicAdd(&cnt[2 * b + (w.x == key ? 0u : 1u)], 1u);
+                if ((cur_valid >> q & 1u) && !hit && !(dbg & 2)) {
+                    const uint32_t e = list[li + q / RPT];
+                    pool[(uint64_t)(e >> 11) * PART_BLOCK + atomicAdd(&miss_cnt[par][q / RPT], 1u)] = cur[q];
+                }
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < Q; q++) cur[q] = nxt[q];
+            cur_valid = nxt_valid;
+        }
+        __syncthreads();
+        if (nl) {
+            const uint32_t last = ((nl - 1) / K2_U) * K2_U, par = (last / K2_U) & 1u;
+            if (t < K2_U) {
+                if (last + t < nl) desc[list[last + t] >> 11] = ((p + 1) << 16) | miss_cnt[par][t];
+                miss_cnt[par][t] = 0;
+            }
+        }
+        __syncthreads();
+    }
+    // flush the slot counters: one atomic per occupied slot
+    uint64_t local = 0;
+    for (uint32_t i = t; i < slice; i += K2_THREADS) {
+        const uint32_t c = cnt[i];
+        if (c) {
+            atomicAdd(&counts[(uint32_t)(lib.slots[(uint64_t)p * slice + i] & ((1ull << gid_bits) - 1ull))], c);
+            local += c;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    __shared__ unsigned long long wsum;
+    if (t == 0) wsum = 0;
+    __syncthreads();
+    if ((t & 63) == 0 && local) atomicAdd(&wsum, (unsigned long long)local);
+    __syncthreads();
+    if (t == 0 && wsum) atomicAdd(matched, wsum);
+}
+
+// ------------------------------------------------------------------------------------------------ K3
+// The rest of Counter::assign for the misses (their Centered-exact probe failed, or their status is
+// non-zero).  A workgroup owns a SEGMENT of K3_SEG consecutive blocks: one wave per block copies the misses
+// from the block fronts into LDS (so that the sparse fronts become one dense array), then every lane
+// resolves K3_R of them at a time:
+//   round A  permute(C), library(P), library(M) issued together;
+//   round B  permute(P), permute(M) issued together, only for records still unresolved after library(P);
+// and the results are taken in the reference's order C-1mm, P-exact, P-1mm, M-exact, M-1mm
+// (src/counter.rs:113-135).  Guide ids go to gids[segment * K3_SEG * BLOCK + i]; seg_cnt[segment] = count.
+#define K3_SEG 4u
+#define K3_THREADS 256u
+#define K3_STAGE 2048u
+#define K3_R 2u
+template <bool ONE_MM>
+__global__ void __launch_bounds__(K3_THREADS) k_resolve_miss(const uint64_t *__restrict__ pool,
+                                                             const uint32_t *__restrict__ desc, uint32_t n_blocks,
+                                                             uint32_t L, sgc_table_view lib, sgc_table_view perm,
+                                                             uint32_t *__restrict__ gids, uint32_t *__restrict__ seg_cnt) {
+    __shared__ uint64_t st[K3_STAGE];
+    __shared__ uint32_t m_[K3_SEG], off_[K3_SEG + 1];
+    const uint32_t t = threadIdx.x, seg = blockIdx.x, b0 = seg * K3_SEG;
+    const uint32_t sh = 2 * (L + 2);
+    const uint64_t smask = (1ull << sh) - 1ull, kmask = sgc_key_mask(L);
+    if (t < K3_SEG) m_[t] = b0 + t < n_blocks ? desc[b0 + t] & DESC_FILL_MASK : 0;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (uint32_t u = 0; u < K3_SEG; u++) { off_[u] = run; run += m_[u]; }
+        off_[K3_SEG] = run;
+        seg_cnt[seg] = run;
+    }
+    __syncthreads();
+    const uint32_t T = off_[K3_SEG];
+    uint32_t *out = gids + (uint64_t)seg * (K3_SEG * PART_BLOCK);
+    for (uint32_t r0 = 0; r0 < T; r0 += K3_STAGE) {
+        {   // stage [r0, r0 + K3_STAGE): wave u copies the front of block u
+            const uint32_t u = t >> 6, lane = t & 63u;
+            const uint64_t *blkp = pool + (uint64_t)(b0 + u) * PART_BLOCK;
+            for (uint32_t j = lane; j < m_[u]; j += 64) {
+                const uint32_t d = off_[u] + j;
+                if (d >= r0 && d < r0 + K3_STAGE) st[d - r0] = __builtin_nontemporal_load(&blkp[j]);
+            }
+        }
+        __syncthreads();
+        const uint32_t cntr = T - r0 < K3_STAGE ? T - r0 : K3_STAGE;
+        for (uint32_t d0 = 0; d0 < cntr; d0 += K3_THREADS * K3_R) {
+            uint64_t rec[K3_R];
+            ulonglong2 a0[K3_R], a1[K3_R], a3[K3_R];
+            uint32_t x[K3_R], hP[K3_R], hM[K3_R], qC[K3_R];
+            bool live[K3_R], fast[K3_R], needB[K3_R];
+#pragma unroll
+            for (uint32_t r = 0; r < K3_R; r++) {
+                const uint32_t d = d0 + r * K3_THREADS + t;
+                live[r] = d < cntr;
+                rec[r] = live[r] ? st[d] : 0;
+                fast[r] = live[r] && (rec[r] >> sh) == 0;
+                x[r] = SGC_NONE;
+            }
+            // round A
+#pragma unroll
+            for (uint32_t r = 0; r < K3_R; r++) {
+                if (!fast[r]) continue;
+                hP[r] = bucket_of(lib, (rec[r] >> 4) & kmask); hM[r] = bucket_of(lib, rec[r] & kmask);
+                a1[r] = load_bucket(lib, hP[r]); a3[r] = load_bucket(lib, hM[r]);
+                if (ONE_MM) { qC[r] = bucket_of(perm, (rec[r] >> 2) & kmask); a0[r] = load_bucket(perm, qC[r]); }
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < K3_R; r++) {
+                needB[r] = false;
+                if (!live[r]) continue;
+                if (!fast[r]) { x[r] = sgc_assign<true>(rec[r] & smask, rec[r] >> sh, L, lib, perm, ONE_MM); continue; }
+                if (ONE_MM) x[r] = finish_find(perm, (rec[r] >> 2) & kmask, qC[r], a0[r]);
+                if (x[r] == SGC_NONE) x[r] = finish_find(lib, (rec[r] >> 4) & kmask, hP[r], a1[r]);
+                needB[r] = x[r] == SGC_NONE;
+            }
+            // round B
+            ulonglong2 b2[K3_R], b4[K3_R];
+            uint32_t qP[K3_R], qM[K3_R];
+            if (ONE_MM) {
+#pragma unroll
+                for (uint32_t r = 0; r < K3_R; r++) {
+                    if (!needB[r]) continue;
+                    qP[r] = bucket_of(perm, (rec[r] >> 4) & kmask); qM[r] = bucket_of(perm, rec[r] & kmask);
+                    b2[r] = load_bucket(perm, qP[r]); b4[r] = load_bucket(perm, qM[r]);
+                }
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < K3_R; r++) {
+                if (needB[r]) {
+                    if (ONE_MM) x[r] = finish_find(perm, (rec[r] >> 4) & kmask, qP[r], b2[r]);
+                    if (x[r] == SGC_NONE) x[r] = finish_find(lib, rec[r] & kmask, hM[r], a3[r]);
+                    if (ONE_MM && x[r] == SGC_NONE) x[r] = finish_find(perm, rec[r] & kmask, qM[r], b4[r]);
+                }
+                if (live[r]) out[r0 + d0 + r * K3_THREADS + t] = x[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K4
+// LDS histogram of the segments' guide ids, one guide-range slice per pass; also tallies the matched reads.
+// Four 256-lane groups walk different segments at once (a segment is short: a few hundred to ~1k ids).
+#define K4_SLICE 36864u
+__global__ void __launch_bounds__(1024) k_hist_segments(const uint32_t *__restrict__ gids, const uint32_t *__restrict__ seg_cnt,
+                                                        uint32_t n_segs, uint32_t n_guides, uint32_t *__restrict__ counts,
+                                                        unsigned long long *__restrict__ matched) {
+    __shared__ uint32_t h[K4_SLICE];
+    const uint32_t t = threadIdx.x;
+    uint64_t local = 0;
+    for (uint32_t base = 0; base < n_guides; base += K4_SLICE) {
+        for (uint32_t j = t; j < K4_SLICE; j += 1024) h[j] = 0;
+        __syncthreads();
+        for (uint32_t sg = blockIdx.x * 4 + (t >> 8); sg < n_segs; sg += gridDim.x * 4) {
+            const uint32_t c = seg_cnt[sg];
+            const uint32_t *src = gids + (uint64_t)sg * (K3_SEG * PART_BLOCK);
+            for (uint32_t i = t & 255u; i < c; i += 256) {
+                const uint32_t r = src[i] - base;
+                if (r < K4_SLICE) { atomicAdd(&h[r], 1u); local++; }
+            }
+        }
+        __syncthreads();
+        const uint32_t lim = n_guides - base < K4_SLICE ? n_guides - base : K4_SLICE;
+        for (uint32_t j = t; j < lim; j += 1024) {
+            const uint32_t v = h[j];
+            if (v) atomicAdd(&counts[base + j], v);
+        }
+        __syncthreads();
+    }
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    __shared__ unsigned long long wsum;
+    if (t == 0) wsum = 0;
+    __syncthreads();
+    if ((t & 63) == 0 && local) atomicAdd(&wsum, (unsigned long long)local);
+    __syncthreads();
+    if (t == 0 && wsum) atomicAdd(matched, wsum);
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+bool sgc_part_supported(const sgc_table_view &lib, bool rec16) {
+    if (rec16 || lib.gid_bits == 0) return false;
+    if (lib.log2_slice > SGC_LDS_LOG2_SLICE || lib.log2_slice < 1) return false;
+    return (lib.log2_slots - lib.log2_slice) <= 6;      // <= PART_MAXP partitions
+}
+
+void sgc_part_plan(uint64_t n, const sgc_table_view &lib, sgc_part_geometry *g) {
+    const uint32_t P = 1u << (lib.log2_slots - lib.log2_slice);
+    uint64_t tiles = (n + PART_TILE - 1) / PART_TILE;
+    uint32_t wgs = (uint32_t)(tiles < 1024 ? (tiles ? tiles : 1) : 1024);
+    uint64_t per = (tiles + wgs - 1) / wgs * PART_TILE;                 // records per K1 workgroup, whole tiles
+    g->k1_wgs = wgs;
+    g->per_wg = per;
+    g->blocks_per_wg = (uint32_t)(per / PART_BLOCK) + P;               // full blocks + one open block per partition
+    g->n_blocks = wgs * g->blocks_per_wg;
+    g->pool_bytes = (uint64_t)g->n_blocks * PART_BLOCK * 8;
+    g->desc_bytes = (uint64_t)g->n_blocks * 4;
+    g->n_segs = (g->n_blocks + K3_SEG - 1) / K3_SEG;
+    g->gids_bytes = (uint64_t)g->n_segs * K3_SEG * PART_BLOCK * 4;
+    g->partitions = P;
+}
+
+void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib,
+                        const sgc_part_geometry &g, uint64_t *pool, uint32_t *desc) {
+    (void)hipMemsetAsync(desc, 0, g.desc_bytes, st);
+    hipLaunchKernelGGL(k_partition, dim3(g.k1_wgs), dim3(256), 0, st, recs, n, g.per_wg, g.blocks_per_wg, L,
+                       lib.log2_slots, lib.log2_slice, pool, desc);
+}
+
+void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_part_geometry &g,
+                        uint64_t *pool, uint32_t *desc, uint32_t *counts, unsigned long long *matched, uint32_t dbg) {
+    const uint32_t G = g.partitions >= 512 ? 1 : 512 / g.partitions;     // two workgroups per CU
+    hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE>), dim3(g.partitions * G), dim3(K2_THREADS), 0, st, pool, desc,
+                       g.n_blocks, G, L, lib, counts, matched, dbg);
+}
+
+void sgc_launch_part_k3(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm,
+                        const sgc_part_geometry &g, const uint64_t *pool, const uint32_t *desc, uint32_t *seg_cnt,
+                        uint32_t *gids) {
+    const unsigned grid = (g.n_blocks + K3_SEG - 1) / K3_SEG;
+    if (one_mm)
+        hipLaunchKernelGGL((k_resolve_miss<true>), dim3(grid), dim3(K3_THREADS), 0, st, pool, desc, g.n_blocks, L, lib, perm, gids, seg_cnt);
+    else
+        hipLaunchKernelGGL((k_resolve_miss<false>), dim3(grid), dim3(K3_THREADS), 0, st, pool, desc, g.n_blocks, L, lib, perm, gids, seg_cnt);
+}
+
+void sgc_launch_part_k4(hipStream_t st, uint32_t n_guides, const sgc_part_geometry &g, const uint32_t *gids,
+                        const uint32_t *seg_cnt, uint32_t *counts, unsigned long long *matched) {
+    const unsigned n_segs = (g.n_blocks + K3_SEG - 1) / K3_SEG;
+    const unsigned grid = n_segs < 4 * 256 ? (n_segs + 3) / 4 : 256;
+    hipLaunchKernelGGL(k_hist_segments, dim3(grid), dim3(1024), 0, st, gids, seg_cnt, n_segs, n_guides, counts, matched);
+}

@@ -22,9 +22,12 @@ static uint32_t ceil_log2(uint64_t x) {
     return l;
 }
 
-static void table_alloc(sgc_host_table &t, uint64_t entries, double max_load, uint32_t gid_bits) {
+static void table_alloc(sgc_host_table &t, uint64_t entries, double max_load, uint32_t gid_bits,
+                        uint32_t max_log2_slice = 0, uint32_t extra_log2 = 0) {
     uint64_t want = (uint64_t)((double)entries / max_load) + 1;
-    t.log2_slots = std::max<uint32_t>(4, ceil_log2(want));
+    t.log2_slots = std::max<uint32_t>(4, ceil_log2(want)) + extra_log2;
+    if (max_log2_slice == 1) max_log2_slice = 2;
+    t.log2_slice = (max_log2_slice && max_log2_slice < t.log2_slots) ? max_log2_slice : t.log2_slots;
     t.gid_bits = gid_bits;
     t.slots.assign(1ull << t.log2_slots, SGC_EMPTY);
     if (gid_bits == 0) t.vals.assign(1ull << t.log2_slots, SGC_NONE); else t.vals.clear();
@@ -32,23 +35,31 @@ static void table_alloc(sgc_host_table &t, uint64_t entries, double max_load, ui
 }
 
 static inline void table_insert(sgc_host_table &t, uint64_t key, uint32_t gid) {
-    const uint64_t mask = (1ull << t.log2_slots) - 1;
-    uint64_t h = sgc_hash(key) >> (64 - t.log2_slots);
-    while (t.slots[h] != SGC_EMPTY) h = (h + 1) & mask;
-    if (t.gid_bits) t.slots[h] = (key << t.gid_bits) | gid;
-    else { t.slots[h] = key; t.vals[h] = gid; }
-    t.entries++;
+    uint32_t b = sgc_home_bucket(key, t.log2_slots);
+    for (;;) {
+        for (uint32_t k = 0; k < 2; k++) {
+            const uint64_t h = 2ull * b + k;
+            if (t.slots[h] != SGC_EMPTY) continue;
+            if (t.gid_bits) t.slots[h] = (key << t.gid_bits) | gid;
+            else { t.slots[h] = key; t.vals[h] = gid; }
+            t.entries++;
+            return;
+        }
+        b = sgc_next_bucket(b, t.log2_slice);
+    }
 }
 
 static inline uint32_t table_find_host(const sgc_host_table &t, uint64_t key) {
-    const uint64_t mask = (1ull << t.log2_slots) - 1;
-    uint64_t h = sgc_hash(key) >> (64 - t.log2_slots);
+    uint32_t b = sgc_home_bucket(key, t.log2_slots);
     for (;;) {
-        const uint64_t s = t.slots[h];
-        if (s == SGC_EMPTY) return SGC_NONE;
-        if (t.gid_bits) { if ((s >> t.gid_bits) == key) return (uint32_t)(s & ((1ull << t.gid_bits) - 1)); }
-        else if (s == key) return t.vals[h];
-        h = (h + 1) & mask;
+        for (uint32_t k = 0; k < 2; k++) {
+            const uint64_t h = 2ull * b + k;
+            const uint64_t s = t.slots[h];
+            if (s == SGC_EMPTY) return SGC_NONE;
+            if (t.gid_bits) { if ((s >> t.gid_bits) == key) return (uint32_t)(s & ((1ull << t.gid_bits) - 1)); }
+            else if (s == key) return t.vals[h];
+        }
+        b = sgc_next_bucket(b, t.log2_slice);
     }
 }
 
@@ -62,8 +73,18 @@ static uint32_t choose_gid_bits(uint32_t n, uint32_t L) {
     return gb;
 }
 
-int sgc_build_library_table(const uint8_t *seqs, uint32_t n, uint32_t L, std::vector<uint64_t> &keys,
-                            sgc_host_table &out, std::string &err) {
+// true if some slice is filled beyond `limit` of its slots (probing must always find a free slot)
+static bool slice_overfull(const std::vector<uint64_t> &keys, uint32_t log2_slots, uint32_t log2_slice, double limit) {
+    if (log2_slice >= log2_slots) return false;
+    std::vector<uint32_t> fill(1ull << (log2_slots - log2_slice), 0);
+    const uint32_t cap = (uint32_t)((double)(1u << log2_slice) * limit);
+    for (uint64_t k : keys)
+        if (++fill[sgc_slice_of(k, log2_slots, log2_slice)] > cap) return true;
+    return false;
+}
+
+int sgc_build_library_table(const uint8_t *seqs, uint32_t n, uint32_t L, uint32_t max_log2_slice,
+                            std::vector<uint64_t> &keys, sgc_host_table &out, std::string &err) {
     if (L == 0 || L > SGC_MAXL) { err = "guide length " + std::to_string(L) + " outside 1.." + std::to_string(SGC_MAXL); return SGC_E_UNSUPPORTED; }
     if (n == 0) { err = "empty library"; return SGC_E_ARG; }
     keys.resize(n);
@@ -73,7 +94,15 @@ int sgc_build_library_table(const uint8_t *seqs, uint32_t n, uint32_t L, std::ve
             return SGC_E_UNSUPPORTED;
         }
     }
-    table_alloc(out, n, 0.4, choose_gid_bits(n, L));
+    // grow the table until no slice is more than 60 % full (hash imbalance between slices)
+    uint32_t extra = 0;
+    for (;; extra++) {
+        table_alloc(out, n, 0.4, choose_gid_bits(n, L), max_log2_slice, extra);
+        if (extra >= 4 || !slice_overfull(keys, out.log2_slots, out.log2_slice, 0.6)) break;
+    }
+    if (slice_overfull(keys, out.log2_slots, out.log2_slice, 0.9)) {   // pathological key set: give up slicing
+        table_alloc(out, n, 0.4, choose_gid_bits(n, L), 0, 0);
+    }
     for (uint32_t i = 0; i < n; i++) {
         if (table_find_host(out, keys[i]) != SGC_NONE) {      // src/library.rs:91-96
             err = "Unexpected duplicate sequence in library found: " + std::string((const char *)seqs + (size_t)i * L, L);

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""A/B timing of count-kernel variants in ONE process (interleaved rounds), on the bench workload.
+
+    python tools/tune.py --reads 100000000 --variants 0,1 --rounds 3 --workload 1mm
+Prints per variant: median/min of Σ kernel time per pass (lookup, hist), and checks every variant
+returns the same count table.
+"""
+import argparse
+import hashlib
+import json
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=100_000_000)
+    ap.add_argument("--guides", type=int, default=100_000)
+    ap.add_argument("--variants", default="0,1")
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--workload", choices=["1mm", "exact"], default="1mm")
+    ap.add_argument("--nocheck", action="store_true")
+    ap.add_argument("--opts", default="", help="extra options k=v,k=v applied to all variants")
+    args = ap.parse_args()
+    import torch
+    from sgcount_amd.workload import DeviceWorkload
+    wl = DeviceWorkload(args.reads, args.guides, 20, one_mismatch=args.workload == "1mm")
+    for kv in filter(None, args.opts.split(",")):
+        k, v = kv.split("=")
+        wl.dl.set_option(k, int(v))
+    specs = {}
+    variants = []
+    for item in args.variants.split(","):
+        v, _, opts = item.partition(":")
+        variants.append(item)
+        specs[item] = (int(v), [kv.split("=") for kv in filter(None, opts.split(";"))])
+    res = {v: {"lookup": [], "hist": [], "wall": [], "part": [], "miss": []} for v in variants}
+    sig = {}
+    wl.dl.timing(True)
+    for r in range(args.rounds + 1):
+        for v in variants:
+            wl.dl.set_option("variant", specs[v][0])
+            wl.dl.set_option("dbg", 0)
+            for k, val in specs[v][1]:
+                wl.dl.set_option(k, int(val))
+            torch.cuda.synchronize()
+            wl.dl.timing(reset=True)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.steps):
+                wl.step()
+            e1.record()
+            torch.cuda.synchronize()
+            t = wl.dl.timing(reset=True)
+            counts, total, matched = wl.result()
+            h = hashlib.sha256(counts.tobytes()).hexdigest()[:12] + ":%d:%d" % (total, matched)
+            sig.setdefault(v, h)
+            assert args.nocheck or sig[v] == h
+            if r == 0:
+                continue  # warm-up round
+            res[v]["lookup"].append(t.lookup_ms / args.steps)
+            res[v]["hist"].append(t.hist_ms / args.steps)
+            res[v]["part"].append(t.part_ms / args.steps)
+            res[v]["miss"].append(t.miss_ms / args.steps)
+            res[v]["wall"].append(e0.elapsed_time(e1) / args.steps)
+    assert args.nocheck or len(set(sig.values())) == 1, "variants disagree: %r" % sig
+    print("reads=%d workload=%s table=%s" % (args.reads, args.workload, next(iter(sig.values()))))
+    for v in variants:
+        d = res[v]
+        print("variant %-22s part %.3f  lookup %.3f (min %.3f)  miss %.3f  hist %.3f (min %.3f)  wall/step %.3f (min %.3f) ms  -> %.1f Greads/s" % (
+            v, statistics.median(d["part"]), statistics.median(d["lookup"]), min(d["lookup"]), statistics.median(d["miss"]),
+            statistics.median(d["hist"]), min(d["hist"]),
+            statistics.median(d["wall"]), min(d["wall"]), args.reads / statistics.median(d["wall"]) / 1e6))
+
+
+if __name__ == "__main__":
+    main()
