@@ -41,6 +41,8 @@ struct sgc_ctx {
     uint64_t *d_lib_slots = nullptr, *d_perm_slots = nullptr;
     uint32_t *d_lib_vals = nullptr, *d_perm_vals = nullptr;
     sgc_table_view v_lib{}, v_perm{};
+    uint64_t *d_bloom_lib = nullptr, *d_bloom_perm = nullptr;
+    sgc_bloom_view b_lib{}, b_perm{};
     uint64_t perm_entries = 0;
     // scratch (grown on demand, stream-ordered reuse)
     void *d_stage = nullptr; size_t stage_cap = 0;      // host -> device staging of pushed buffers
@@ -148,8 +150,10 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
             if (rc) return rc;
             rc = ensure(&c->d_aux, &c->aux_cap, ((size_t)g.n_segs + 1) * 4);
             if (rc) return rc;
-            { timed t(c, T_MISS); sgc_launch_part_k3(c->stream, c->L, c->v_lib, c->v_perm, c->one_mm, g, pool, desc,
-                                                     (uint32_t *)c->d_aux, (uint32_t *)c->d_gids); }
+            { timed t(c, T_MISS); sgc_launch_part_generic(c->stream, c->L, c->v_lib, c->v_perm, c->one_mm, g, pool, desc,
+                                                          s->d_c32, s->d_matched); }
+            { timed t(c, T_MISS); sgc_launch_part_k3(c->stream, c->L, c->v_lib, c->v_perm, c->one_mm, c->b_lib, c->b_perm, g, pool, desc,
+                                                     (uint32_t *)c->d_aux, (uint32_t *)c->d_gids, c->dbg); }
             { timed t(c, T_HIST); sgc_launch_part_k4(c->stream, c->n, g, (const uint32_t *)c->d_gids,
                                                      (const uint32_t *)c->d_aux, s->d_c32, s->d_matched); }
         } else if (c->variant == 0) {
@@ -220,6 +224,10 @@ static void free_tables(sgc_ctx *c) {
     if (c->d_perm_slots) hipFree(c->d_perm_slots);
     if (c->d_lib_vals) hipFree(c->d_lib_vals);
     if (c->d_perm_vals) hipFree(c->d_perm_vals);
+    if (c->d_bloom_lib) hipFree(c->d_bloom_lib);
+    if (c->d_bloom_perm) hipFree(c->d_bloom_perm);
+    c->d_bloom_lib = c->d_bloom_perm = nullptr;
+    c->b_lib = sgc_bloom_view{}; c->b_perm = sgc_bloom_view{};
     c->d_lib_slots = c->d_perm_slots = nullptr;
     c->d_lib_vals = c->d_perm_vals = nullptr;
     c->has_lib = false;
@@ -267,6 +275,17 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
     return fail(SGC_E_ARG, std::string("sgc_set_option: unknown key ") + key);
 }
 
+static int upload_bloom(const std::vector<uint64_t> &keys, uint32_t log2_words, uint64_t **d_words, sgc_bloom_view *v,
+                        hipStream_t st) {
+    std::vector<uint64_t> words;
+    sgc_build_bloom(keys, log2_words, words);
+    HIP_TRY(hipMalloc((void **)d_words, words.size() * 8));
+    HIP_TRY(hipMemcpyAsync(*d_words, words.data(), words.size() * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    v->words = *d_words; v->log2_words = log2_words; v->pad_ = 0;
+    return SGC_OK;
+}
+
 static int upload_table(const sgc_host_table &h, uint64_t **d_slots, uint32_t **d_vals, sgc_table_view *v,
                         hipStream_t st) {
     const size_t nslots = h.slots.size();
@@ -294,13 +313,20 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
     if (rc != SGC_OK) return fail(rc, "sgc_set_library: " + err);
     rc = upload_table(h_lib, &c->d_lib_slots, &c->d_lib_vals, &c->v_lib, c->stream);
     if (rc != SGC_OK) { free_tables(c); return rc; }
+    rc = upload_bloom(keys, SGC_LIB_BLOOM_LOG2_WORDS, &c->d_bloom_lib, &c->b_lib, c->stream);
+    if (rc != SGC_OK) { free_tables(c); return rc; }
     c->v_perm = sgc_table_view{nullptr, nullptr, 0, h_lib.gid_bits, 0, 0};
     c->perm_entries = 0;
     if (enable_1mm) {
-        sgc_build_permute_table(keys, L, h_lib, h_perm);
+        std::vector<uint64_t> child_keys;
+        sgc_build_permute_table(keys, L, h_lib, h_perm, &child_keys);
         rc = upload_table(h_perm, &c->d_perm_slots, &c->d_perm_vals, &c->v_perm, c->stream);
         if (rc != SGC_OK) { free_tables(c); return rc; }
         c->perm_entries = h_perm.entries;
+        // ~5.6 bits per child: 6.0 M children -> 2^19 words = 4 MiB (the XCD L2 size)
+        rc = upload_bloom(child_keys, sgc_bloom_log2_words(child_keys.size(), 4, 10, 24), &c->d_bloom_perm, &c->b_perm,
+                          c->stream);
+        if (rc != SGC_OK) { free_tables(c); return rc; }
     }
     c->n = n; c->L = L; c->one_mm = enable_1mm != 0; c->rec16 = L > SGC_REC8_MAXL; c->has_lib = true;
     return SGC_OK;

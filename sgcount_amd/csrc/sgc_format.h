@@ -86,6 +86,15 @@ SGC_HD uint32_t sgc_slice_of(uint64_t key, uint32_t log2_slots, uint32_t log2_sl
     return sgc_home_bucket(key, log2_slots) >> (log2_slice - 1);
 }
 
+// Blocked Bloom filter: one 64-bit word per key, two bits in it.  A clear bit proves the key is absent;
+// the count path uses it to skip probes that would miss (most Plus/Minus/permute probes do).
+SGC_HD uint64_t sgc_hash2(uint64_t key) {
+    key ^= key >> 31;
+    return key * 0xD6E8FEB86659FD93ull;
+}
+SGC_HD uint32_t sgc_bloom_word(uint64_t h2, uint32_t log2_words) { return (uint32_t)(h2 >> (64 - log2_words)); }
+SGC_HD uint64_t sgc_bloom_mask(uint64_t h2) { return (1ull << (h2 & 63)) | (1ull << ((h2 >> 6) & 63)); }
+
 // Builds one record from a read.  `emit(span_bits, status)` style is avoided to keep this usable in
 // kernels: returns span and status through references.
 SGC_HD void sgc_pack_one(const uint8_t *seq, uint64_t n, uint32_t L, int reverse, uint32_t o, int recursion,

@@ -8,6 +8,14 @@
 // slots per library-table slice staged in LDS by the partitioned path: 2^12 x 8 B = 32 KiB of keys plus
 // 16 KiB of counters, so that two 1024-lane workgroups share a CU's 160 KiB
 #define SGC_LDS_LOG2_SLICE 12u
+// 64-bit words of the library Bloom filter the miss resolver stages in LDS (2^13 x 8 B = 64 KiB)
+#define SGC_LIB_BLOOM_LOG2_WORDS 13u
+
+struct sgc_bloom_view {
+    const uint64_t *words;
+    uint32_t log2_words;
+    uint32_t pad_;
+};
 
 void sgc_launch_count_direct(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, bool rec16,
                              const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm, uint32_t *counts,
@@ -37,7 +45,10 @@ void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32
 void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_part_geometry &g,
                         uint64_t *pool, uint32_t *desc, uint32_t *counts, unsigned long long *matched, uint32_t dbg);
 void sgc_launch_part_k3(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm,
-                        const sgc_part_geometry &g, const uint64_t *pool, const uint32_t *desc, uint32_t *seg_cnt,
-                        uint32_t *gids);
+                        const sgc_bloom_view &bloom_lib, const sgc_bloom_view &bloom_perm, const sgc_part_geometry &g,
+                        const uint64_t *pool, const uint32_t *desc, uint32_t *seg_cnt, uint32_t *gids, uint32_t dbg);
+void sgc_launch_part_generic(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm,
+                             const sgc_part_geometry &g, const uint64_t *pool, const uint32_t *desc, uint32_t *counts,
+                             unsigned long long *matched);
 void sgc_launch_part_k4(hipStream_t st, uint32_t n_guides, const sgc_part_geometry &g, const uint32_t *gids,
                         const uint32_t *seg_cnt, uint32_t *counts, unsigned long long *matched);

@@ -30,12 +30,19 @@
 
 #define PART_TILE 2048u          // records staged per tile in K1 (== block size)
 #define PART_BLOCK 2048u         // records per block
-#define PART_MAXP 64u            // max partitions (library slices)
+#define PART_MAXP 64u            // max library slices; partition index PART_MAXP' = P_lib is the generic one
+#define PART_ARR (PART_MAXP + 1u)
 #define DESC_FILL_MASK 0xFFFFu
 
 static_assert(PART_TILE <= PART_BLOCK, "a tile must fit one block");
 
-__device__ __forceinline__ uint32_t part_of(uint64_t rec, uint64_t kmask, uint32_t log2_slots, uint32_t log2_slice) {
+// Partition of a record: the library slice of its Centered key, or — for records whose status is non-zero
+// (an 'N', a dead window, a short read; ~2 % of reads) — the extra "generic" partition P_lib.  Those records
+// need the serial generic chain (sgc_assign); kept apart, they are resolved by full waves in k_generic
+// instead of stalling one or two lanes of almost every wave of the fast kernels.
+__device__ __forceinline__ uint32_t part_of(uint64_t rec, uint64_t kmask, uint32_t sh, uint32_t log2_slots,
+                                            uint32_t log2_slice) {
+    if ((rec >> sh) != 0) return 1u << (log2_slots - log2_slice);
     return sgc_slice_of((rec >> 2) & kmask, log2_slots, log2_slice);
 }
 
@@ -45,20 +52,21 @@ __global__ void __launch_bounds__(256) k_partition(const uint64_t *__restrict__ 
                                                    uint32_t log2_slice, uint64_t *__restrict__ pool,
                                                    uint32_t *__restrict__ desc) {
     __shared__ uint64_t stage[PART_TILE];
-    __shared__ uint32_t cnt[PART_MAXP], start[PART_MAXP], blk[PART_MAXP], fill[PART_MAXP];
-    __shared__ uint32_t dst_a[PART_MAXP], dst_b[PART_MAXP], split[PART_MAXP];
+    __shared__ uint32_t cnt[PART_ARR], start[PART_ARR], blk[PART_ARR], fill[PART_ARR];
+    __shared__ uint32_t dst_a[PART_ARR], dst_b[PART_ARR], split[PART_ARR];
     __shared__ uint32_t next_free;
-    const uint32_t P = 1u << (log2_slots - log2_slice), t = threadIdx.x;
+    const uint32_t P = 1u << (log2_slots - log2_slice), t = threadIdx.x;     // library slices; partition P = generic
+    const uint32_t sh = 2 * (L + 2);
     const uint64_t kmask = sgc_key_mask(L);
     const uint64_t lo = (uint64_t)blockIdx.x * per_wg;
     const uint64_t hi = lo + per_wg < n ? lo + per_wg : n;
     const uint32_t block0 = blockIdx.x * blocks_per_wg;
-    if (t < PART_MAXP) { blk[t] = 0xFFFFFFFFu; fill[t] = PART_BLOCK; }
+    if (t < PART_ARR) { blk[t] = 0xFFFFFFFFu; fill[t] = PART_BLOCK; }
     if (t == 0) next_free = 0;
     __syncthreads();
     for (uint64_t base = lo; base < hi; base += PART_TILE) {
         const uint32_t m = (uint32_t)(hi - base < PART_TILE ? hi - base : PART_TILE);
-        if (t < PART_MAXP) cnt[t] = 0;
+        if (t < PART_ARR) cnt[t] = 0;
         __syncthreads();
         uint64_t rec[PART_TILE / 256];
         uint32_t pr[PART_TILE / 256];     // partition << 16 | rank inside the tile
@@ -71,7 +79,7 @@ __global__ void __launch_bounds__(256) k_partition(const uint64_t *__restrict__ 
         for (uint32_t k = 0; k < PART_TILE / 256; k++) {
             const uint32_t j = k * 256 + t;
             if (j < m) {
-                const uint32_t p = part_of(rec[k], kmask, log2_slots, log2_slice);
+                const uint32_t p = part_of(rec[k], kmask, sh, log2_slots, log2_slice);
                 pr[k] = (p << 16) | atomicAdd(&cnt[p], 1u);
             }
         }
@@ -79,27 +87,36 @@ __global__ void __launch_bounds__(256) k_partition(const uint64_t *__restrict__ 
         // one lane per partition: exclusive scan of the tile counts, and where the tile's run goes.  A run
         // first tops up the partition's open block, the remainder opens a new one, so every closed block is
         // full and a workgroup never needs more than per_wg / BLOCK + P blocks.
-        if (t < 64) {
-            const uint32_t c = t < P ? cnt[t] : 0;
-            uint32_t incl = c;
+        if (t < 64 || t == 64) {
+            // lanes 0..63: library slices (scanned by wave 0); lane 64 (wave 1): the generic partition, which
+            // starts where the slices end
+            const uint32_t q = t < 64 ? t : P;
+            const uint32_t c = (t < P || t == 64) ? cnt[q] : 0;
+            uint32_t st0;
+            if (t < 64) {
+                uint32_t incl = c;
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t v = __shfl_up(incl, off, 64);
-                if ((int)t >= off) incl += v;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t v = __shfl_up(incl, off, 64);
+                    if ((int)t >= off) incl += v;
+                }
+                st0 = incl - c;
+            } else {
+                st0 = m - c;
             }
-            if (t < P) {
-                start[t] = incl - c;
+            if (t < P || t == 64) {
+                start[q] = st0;
                 if (c) {
-                    const uint32_t room = PART_BLOCK - fill[t];          // 0 when no block is open
+                    const uint32_t room = PART_BLOCK - fill[q];          // 0 when no block is open
                     const uint32_t head = c < room ? c : room;
-                    split[t] = head;
-                    dst_a[t] = head ? blk[t] * PART_BLOCK + fill[t] : 0;
-                    fill[t] += head;
+                    split[q] = head;
+                    dst_a[q] = head ? blk[q] * PART_BLOCK + fill[q] : 0;
+                    fill[q] += head;
                     if (c > head) {
-                        if (blk[t] != 0xFFFFFFFFu) desc[blk[t]] = ((t + 1) << 16) | PART_BLOCK;    // close, full
-                        blk[t] = block0 + atomicAdd(&next_free, 1u);
-                        dst_b[t] = blk[t] * PART_BLOCK;
-                        fill[t] = c - head;
+                        if (blk[q] != 0xFFFFFFFFu) desc[blk[q]] = ((q + 1) << 16) | PART_BLOCK;    // close, full
+                        blk[q] = block0 + atomicAdd(&next_free, 1u);
+                        dst_b[q] = blk[q] * PART_BLOCK;
+                        fill[q] = c - head;
                     }
                 }
             }
@@ -113,14 +130,14 @@ __global__ void __launch_bounds__(256) k_partition(const uint64_t *__restrict__ 
         __syncthreads();
         for (uint32_t j = t; j < m; j += 256) {
             const uint64_t r = stage[j];
-            const uint32_t p = part_of(r, kmask, log2_slots, log2_slice);
+            const uint32_t p = part_of(r, kmask, sh, log2_slots, log2_slice);
             const uint32_t rank = j - start[p];
             const uint64_t at = rank < split[p] ? (uint64_t)dst_a[p] + rank : (uint64_t)dst_b[p] + (rank - split[p]);
             pool[at] = r;
         }
         __syncthreads();
     }
-    if (t < P && blk[t] != 0xFFFFFFFFu) desc[blk[t]] = ((t + 1) << 16) | fill[t];
+    if (t <= P && blk[t] != 0xFFFFFFFFu) desc[blk[t]] = ((t + 1) << 16) | fill[t];
 }
 
 // ------------------------------------------------------------------------------------------------ K2
@@ -258,28 +275,45 @@ __global__ void __launch_bounds__(K2_THREADS) k_count_slices(uint64_t *__restric
 
 // ------------------------------------------------------------------------------------------------ K3
 // The rest of Counter::assign for the misses (their Centered-exact probe failed, or their status is
-// non-zero).  A workgroup owns a SEGMENT of K3_SEG consecutive blocks: one wave per block copies the misses
-// from the block fronts into LDS (so that the sparse fronts become one dense array), then every lane
-// resolves K3_R of them at a time:
-//   round A  permute(C), library(P), library(M) issued together;
-//   round B  permute(P), permute(M) issued together, only for records still unresolved after library(P);
+// non-zero).  Every gather of this kernel that leaves the XCD's L2 costs ~5x an L2 hit, and most probes of
+// this stage MISS (a junk read probes the library twice and the permute table three times for nothing), so
+// probes are screened by Bloom filters first: the library's (64 KiB) is staged in LDS, the permute table's
+// (~4 MiB) is read through L2.  A clear bit proves absence, a set bit is followed by the real probe, so the
+// outcome is exactly the reference's.
+// A workgroup owns a SEGMENT of K3_SEG consecutive blocks: one wave per block copies the misses from the
+// block fronts into LDS (the sparse fronts become one dense array); every lane then resolves K3_R at a time:
+//   round A   filter(permute, C) + library(P) + library(M) buckets (the latter two if the LDS filter passes)
+//   round A'  permute(C) bucket if its filter passed
+//   round B   filter(permute, P), filter(permute, M) — only for records still unresolved after library(P)
+//   round B'  permute(P), permute(M) buckets if their filters passed
 // and the results are taken in the reference's order C-1mm, P-exact, P-1mm, M-exact, M-1mm
 // (src/counter.rs:113-135).  Guide ids go to gids[segment * K3_SEG * BLOCK + i]; seg_cnt[segment] = count.
-#define K3_SEG 4u
-#define K3_THREADS 256u
-#define K3_STAGE 2048u
+#define K3_SEG 16u
+#define K3_THREADS 1024u
+#define K3_STAGE 8192u
 #define K3_R 2u
-template <bool ONE_MM>
+__device__ __forceinline__ bool bloom_hit(uint64_t word, uint64_t h2) {
+    const uint64_t m = sgc_bloom_mask(h2);
+    return (word & m) == m;
+}
+template <bool ONE_MM, bool PBLOOM>
 __global__ void __launch_bounds__(K3_THREADS) k_resolve_miss(const uint64_t *__restrict__ pool,
                                                              const uint32_t *__restrict__ desc, uint32_t n_blocks,
-                                                             uint32_t L, sgc_table_view lib, sgc_table_view perm,
-                                                             uint32_t *__restrict__ gids, uint32_t *__restrict__ seg_cnt) {
+                                                             uint32_t p_generic, uint32_t L, sgc_table_view lib,
+                                                             sgc_table_view perm, sgc_bloom_view bl, sgc_bloom_view bp,
+                                                             uint32_t *__restrict__ gids, uint32_t *__restrict__ seg_cnt,
+                                                             uint32_t dbg) {
     __shared__ uint64_t st[K3_STAGE];
-    __shared__ uint32_t m_[K3_SEG], off_[K3_SEG + 1];
+    __shared__ uint64_t lbf[1u << SGC_LIB_BLOOM_LOG2_WORDS];
+    __shared__ uint32_t m_[K3_SEG], off_[K3_SEG + 1], n_fast, n_slow;
     const uint32_t t = threadIdx.x, seg = blockIdx.x, b0 = seg * K3_SEG;
     const uint32_t sh = 2 * (L + 2);
     const uint64_t smask = (1ull << sh) - 1ull, kmask = sgc_key_mask(L);
-    if (t < K3_SEG) m_[t] = b0 + t < n_blocks ? desc[b0 + t] & DESC_FILL_MASK : 0;
+    if (t < K3_SEG) {          // the generic partition's blocks belong to k_generic
+        const uint32_t d = b0 + t < n_blocks ? desc[b0 + t] : 0;
+        m_[t] = (d >> 16) == p_generic + 1 ? 0 : d & DESC_FILL_MASK;
+    }
+    if (!(dbg & 16)) for (uint32_t i = t; i < (1u << SGC_LIB_BLOOM_LOG2_WORDS); i += K3_THREADS) lbf[i] = bl.words[i];
     __syncthreads();
     if (t == 0) {
         uint32_t run = 0;
@@ -291,69 +325,138 @@ __global__ void __launch_bounds__(K3_THREADS) k_resolve_miss(const uint64_t *__r
     const uint32_t T = off_[K3_SEG];
     uint32_t *out = gids + (uint64_t)seg * (K3_SEG * PART_BLOCK);
     for (uint32_t r0 = 0; r0 < T; r0 += K3_STAGE) {
-        {   // stage [r0, r0 + K3_STAGE): wave u copies the front of block u
+        // stage [r0, r0 + K3_STAGE): wave u copies the front of block u.  Records that need the generic chain
+        // (status != 0: an 'N', a dead window — ~2 % of reads) are packed at the END of the stage and resolved
+        // in their own dense sweep: inline they would make almost every wave walk the serial generic chain
+        // for one or two lanes.
+        if (t == 0) { n_fast = 0; n_slow = 0; }
+        __syncthreads();
+        {
             const uint32_t u = t >> 6, lane = t & 63u;
             const uint64_t *blkp = pool + (uint64_t)(b0 + u) * PART_BLOCK;
             for (uint32_t j = lane; j < m_[u]; j += 64) {
                 const uint32_t d = off_[u] + j;
-                if (d >= r0 && d < r0 + K3_STAGE) st[d - r0] = __builtin_nontemporal_load(&blkp[j]);
+                if (d >= r0 && d < r0 + K3_STAGE) {
+                    const uint64_t rec = __builtin_nontemporal_load(&blkp[j]);
+                    if ((rec >> sh) == 0 && !(dbg & 128)) st[atomicAdd(&n_fast, 1u)] = rec;
+                    else st[K3_STAGE - 1u - atomicAdd(&n_slow, 1u)] = rec;
+                }
             }
         }
         __syncthreads();
-        const uint32_t cntr = T - r0 < K3_STAGE ? T - r0 : K3_STAGE;
+        const uint32_t cntr = n_fast, cnts = n_slow;
+        for (uint32_t k = t; k < cnts; k += K3_THREADS) {
+            const uint64_t rec = st[K3_STAGE - 1u - k];
+            out[r0 + cntr + k] = (dbg & 128) ? SGC_NONE : sgc_assign<true>(rec & smask, rec >> sh, L, lib, perm, ONE_MM);
+        }
         for (uint32_t d0 = 0; d0 < cntr; d0 += K3_THREADS * K3_R) {
-            uint64_t rec[K3_R];
-            ulonglong2 a0[K3_R], a1[K3_R], a3[K3_R];
-            uint32_t x[K3_R], hP[K3_R], hM[K3_R], qC[K3_R];
-            bool live[K3_R], fast[K3_R], needB[K3_R];
+            uint64_t rec[K3_R], fC[K3_R];
+            ulonglong2 a1[K3_R], a3[K3_R];
+            uint32_t x[K3_R], hP[K3_R], hM[K3_R];
+            bool live[K3_R], needB[K3_R], mP[K3_R], mM[K3_R];
 #pragma unroll
             for (uint32_t r = 0; r < K3_R; r++) {
                 const uint32_t d = d0 + r * K3_THREADS + t;
                 live[r] = d < cntr;
                 rec[r] = live[r] ? st[d] : 0;
-                fast[r] = live[r] && (rec[r] >> sh) == 0;
                 x[r] = SGC_NONE;
+                mP[r] = mM[r] = needB[r] = false;
             }
             // round A
 #pragma unroll
             for (uint32_t r = 0; r < K3_R; r++) {
-                if (!fast[r]) continue;
-                hP[r] = bucket_of(lib, (rec[r] >> 4) & kmask); hM[r] = bucket_of(lib, rec[r] & kmask);
-                a1[r] = load_bucket(lib, hP[r]); a3[r] = load_bucket(lib, hM[r]);
-                if (ONE_MM) { qC[r] = bucket_of(perm, (rec[r] >> 2) & kmask); a0[r] = load_bucket(perm, qC[r]); }
+                if (!live[r]) continue;
+                const uint64_t keyP = (rec[r] >> 4) & kmask, keyM = rec[r] & kmask;
+                const uint64_t h2P = sgc_hash2(keyP), h2M = sgc_hash2(keyM);
+                mP[r] = bloom_hit(lbf[sgc_bloom_word(h2P, SGC_LIB_BLOOM_LOG2_WORDS)], h2P);
+                mM[r] = bloom_hit(lbf[sgc_bloom_word(h2M, SGC_LIB_BLOOM_LOG2_WORDS)], h2M);
+                if (mP[r]) { hP[r] = bucket_of(lib, keyP); a1[r] = load_bucket(lib, hP[r]); }
+                if (mM[r]) { hM[r] = bucket_of(lib, keyM); a3[r] = load_bucket(lib, hM[r]); }
+                if (ONE_MM && PBLOOM) fC[r] = bp.words[sgc_bloom_word(sgc_hash2((rec[r] >> 2) & kmask), bp.log2_words)];
+            }
+            // round A'
+            ulonglong2 a0[K3_R];
+            uint32_t qC[K3_R];
+            bool pC[K3_R];
+#pragma unroll
+            for (uint32_t r = 0; r < K3_R; r++) {
+                pC[r] = false;
+                if (!ONE_MM || !live[r]) continue;
+                const uint64_t keyC = (rec[r] >> 2) & kmask;
+                pC[r] = (!PBLOOM || bloom_hit(fC[r], sgc_hash2(keyC))) && !(dbg & 64);
+                if (pC[r]) { qC[r] = bucket_of(perm, keyC); a0[r] = load_bucket(perm, qC[r]); }
             }
 #pragma unroll
             for (uint32_t r = 0; r < K3_R; r++) {
-                needB[r] = false;
                 if (!live[r]) continue;
-                if (!fast[r]) { x[r] = sgc_assign<true>(rec[r] & smask, rec[r] >> sh, L, lib, perm, ONE_MM); continue; }
-                if (ONE_MM) x[r] = finish_find(perm, (rec[r] >> 2) & kmask, qC[r], a0[r]);
-                if (x[r] == SGC_NONE) x[r] = finish_find(lib, (rec[r] >> 4) & kmask, hP[r], a1[r]);
-                needB[r] = x[r] == SGC_NONE;
+                if (pC[r]) x[r] = finish_find(perm, (rec[r] >> 2) & kmask, qC[r], a0[r]);
+                if (x[r] == SGC_NONE && mP[r]) x[r] = finish_find(lib, (rec[r] >> 4) & kmask, hP[r], a1[r]);
+                needB[r] = x[r] == SGC_NONE && !(dbg & 32);
             }
             // round B
-            ulonglong2 b2[K3_R], b4[K3_R];
-            uint32_t qP[K3_R], qM[K3_R];
-            if (ONE_MM) {
+            uint64_t fP[K3_R], fM[K3_R];
+            if (ONE_MM && PBLOOM) {
 #pragma unroll
                 for (uint32_t r = 0; r < K3_R; r++) {
                     if (!needB[r]) continue;
-                    qP[r] = bucket_of(perm, (rec[r] >> 4) & kmask); qM[r] = bucket_of(perm, rec[r] & kmask);
-                    b2[r] = load_bucket(perm, qP[r]); b4[r] = load_bucket(perm, qM[r]);
+                    fP[r] = bp.words[sgc_bloom_word(sgc_hash2((rec[r] >> 4) & kmask), bp.log2_words)];
+                    fM[r] = bp.words[sgc_bloom_word(sgc_hash2(rec[r] & kmask), bp.log2_words)];
                 }
+            }
+            // round B'
+            ulonglong2 b2[K3_R], b4[K3_R];
+            uint32_t qP[K3_R], qM[K3_R];
+            bool pP[K3_R], pM[K3_R];
+#pragma unroll
+            for (uint32_t r = 0; r < K3_R; r++) {
+                pP[r] = pM[r] = false;
+                if (!ONE_MM || !needB[r]) continue;
+                const uint64_t keyP = (rec[r] >> 4) & kmask, keyM = rec[r] & kmask;
+                pP[r] = !PBLOOM || bloom_hit(fP[r], sgc_hash2(keyP));
+                pM[r] = !PBLOOM || bloom_hit(fM[r], sgc_hash2(keyM));
+                if (pP[r]) { qP[r] = bucket_of(perm, keyP); b2[r] = load_bucket(perm, qP[r]); }
+                if (pM[r]) { qM[r] = bucket_of(perm, keyM); b4[r] = load_bucket(perm, qM[r]); }
             }
 #pragma unroll
             for (uint32_t r = 0; r < K3_R; r++) {
                 if (needB[r]) {
-                    if (ONE_MM) x[r] = finish_find(perm, (rec[r] >> 4) & kmask, qP[r], b2[r]);
-                    if (x[r] == SGC_NONE) x[r] = finish_find(lib, rec[r] & kmask, hM[r], a3[r]);
-                    if (ONE_MM && x[r] == SGC_NONE) x[r] = finish_find(perm, rec[r] & kmask, qM[r], b4[r]);
+                    if (pP[r]) x[r] = finish_find(perm, (rec[r] >> 4) & kmask, qP[r], b2[r]);
+                    if (x[r] == SGC_NONE && mM[r]) x[r] = finish_find(lib, rec[r] & kmask, hM[r], a3[r]);
+                    if (x[r] == SGC_NONE && pM[r]) x[r] = finish_find(perm, rec[r] & kmask, qM[r], b4[r]);
                 }
                 if (live[r]) out[r0 + d0 + r * K3_THREADS + t] = x[r];
             }
         }
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------------------------------------ Kg
+// The generic partition: the full Counter::assign chain (sgc_assign), one record per lane, full waves.
+// Workgroup w looks at the descriptors of K1 workgroup w's block range only.  ~2 % of the reads end up
+// here, about half of them match: their counts go straight to the count vector with device-scope atomics.
+template <bool ONE_MM>
+__global__ void __launch_bounds__(256) k_generic(const uint64_t *__restrict__ pool, const uint32_t *__restrict__ desc,
+                                                 uint32_t blocks_per_wg, uint32_t p_generic, uint32_t L,
+                                                 sgc_table_view lib, sgc_table_view perm, uint32_t *__restrict__ counts,
+                                                 unsigned long long *__restrict__ matched) {
+    const uint32_t sh = 2 * (L + 2), t = threadIdx.x;
+    const uint64_t smask = (1ull << sh) - 1ull;
+    uint64_t local = 0;
+    for (uint32_t k = 0; k < blocks_per_wg; k++) {
+        const uint32_t b = blockIdx.x * blocks_per_wg + k;
+        const uint32_t d = desc[b];
+        if ((d >> 16) != p_generic + 1) continue;
+        const uint32_t m = d & DESC_FILL_MASK;
+        const uint64_t *blkp = pool + (uint64_t)b * PART_BLOCK;
+        for (uint32_t j = t; j < m; j += 256) {
+            const uint64_t rec = blkp[j];
+            const uint32_t x = sgc_assign<true>(rec & smask, rec >> sh, L, lib, perm, ONE_MM);
+            if (x != SGC_NONE) { atomicAdd(&counts[x], 1u); local++; }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((t & 63) == 0 && local) atomicAdd(matched, (unsigned long long)local);
 }
 
 // ------------------------------------------------------------------------------------------------ K4
@@ -408,7 +511,7 @@ void sgc_part_plan(uint64_t n, const sgc_table_view &lib, sgc_part_geometry *g) 
     uint64_t per = (tiles + wgs - 1) / wgs * PART_TILE;                 // records per K1 workgroup, whole tiles
     g->k1_wgs = wgs;
     g->per_wg = per;
-    g->blocks_per_wg = (uint32_t)(per / PART_BLOCK) + P;               // full blocks + one open block per partition
+    g->blocks_per_wg = (uint32_t)(per / PART_BLOCK) + P + 1;           // full blocks + one open block per partition (+ generic)
     g->n_blocks = wgs * g->blocks_per_wg;
     g->pool_bytes = (uint64_t)g->n_blocks * PART_BLOCK * 8;
     g->desc_bytes = (uint64_t)g->n_blocks * 4;
@@ -432,13 +535,29 @@ void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, c
 }
 
 void sgc_launch_part_k3(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm,
-                        const sgc_part_geometry &g, const uint64_t *pool, const uint32_t *desc, uint32_t *seg_cnt,
-                        uint32_t *gids) {
+                        const sgc_bloom_view &bloom_lib, const sgc_bloom_view &bloom_perm, const sgc_part_geometry &g,
+                        const uint64_t *pool, const uint32_t *desc, uint32_t *seg_cnt, uint32_t *gids, uint32_t dbg) {
     const unsigned grid = (g.n_blocks + K3_SEG - 1) / K3_SEG;
-    if (one_mm)
-        hipLaunchKernelGGL((k_resolve_miss<true>), dim3(grid), dim3(K3_THREADS), 0, st, pool, desc, g.n_blocks, L, lib, perm, gids, seg_cnt);
+    if (one_mm && (dbg & 256))
+        hipLaunchKernelGGL((k_resolve_miss<true, false>), dim3(grid), dim3(K3_THREADS), 0, st, pool, desc, g.n_blocks, g.partitions,
+                           L, lib, perm, bloom_lib, bloom_perm, gids, seg_cnt, dbg);
+    else if (one_mm)
+        hipLaunchKernelGGL((k_resolve_miss<true, true>), dim3(grid), dim3(K3_THREADS), 0, st, pool, desc, g.n_blocks, g.partitions,
+                           L, lib, perm, bloom_lib, bloom_perm, gids, seg_cnt, dbg);
     else
-        hipLaunchKernelGGL((k_resolve_miss<false>), dim3(grid), dim3(K3_THREADS), 0, st, pool, desc, g.n_blocks, L, lib, perm, gids, seg_cnt);
+        hipLaunchKernelGGL((k_resolve_miss<false, false>), dim3(grid), dim3(K3_THREADS), 0, st, pool, desc, g.n_blocks, g.partitions,
+                           L, lib, perm, bloom_lib, bloom_perm, gids, seg_cnt, dbg);
+}
+
+void sgc_launch_part_generic(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm,
+                             const sgc_part_geometry &g, const uint64_t *pool, const uint32_t *desc, uint32_t *counts,
+                             unsigned long long *matched) {
+    if (one_mm)
+        hipLaunchKernelGGL((k_generic<true>), dim3(g.k1_wgs), dim3(256), 0, st, pool, desc, g.blocks_per_wg, g.partitions, L,
+                           lib, perm, counts, matched);
+    else
+        hipLaunchKernelGGL((k_generic<false>), dim3(g.k1_wgs), dim3(256), 0, st, pool, desc, g.blocks_per_wg, g.partitions, L,
+                           lib, perm, counts, matched);
 }
 
 void sgc_launch_part_k4(hipStream_t st, uint32_t n_guides, const sgc_part_geometry &g, const uint32_t *gids,

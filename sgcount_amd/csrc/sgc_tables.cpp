@@ -113,8 +113,21 @@ int sgc_build_library_table(const uint8_t *seqs, uint32_t n, uint32_t L, uint32_
     return SGC_OK;
 }
 
+void sgc_build_bloom(const std::vector<uint64_t> &keys, uint32_t log2_words, std::vector<uint64_t> &out) {
+    out.assign(1ull << log2_words, 0);
+    for (uint64_t k : keys) {
+        const uint64_t h = sgc_hash2(k);
+        out[sgc_bloom_word(h, log2_words)] |= sgc_bloom_mask(h);
+    }
+}
+
+uint32_t sgc_bloom_log2_words(uint64_t n_keys, uint32_t bits_per_key, uint32_t min_log2, uint32_t max_log2) {
+    const uint32_t l = ceil_log2((n_keys * bits_per_key + 63) / 64 + 1);
+    return std::min(std::max(l, min_log2), max_log2);
+}
+
 void sgc_build_permute_table(const std::vector<uint64_t> &keys, uint32_t L, const sgc_host_table &lib,
-                             sgc_host_table &out) {
+                             sgc_host_table &out, std::vector<uint64_t> *child_keys) {
     const uint32_t n = (uint32_t)keys.size();
     const uint32_t gb = lib.gid_bits;
     // all (child, parent) pairs: 3 ACGT substitutions per position (src/permutes.rs:78-107 minus the 'N' column)
@@ -138,4 +151,8 @@ void sgc_build_permute_table(const std::vector<uint64_t> &keys, uint32_t L, cons
     }
     table_alloc(out, keep.size(), 0.5, gb);
     for (const auto &kv : keep) table_insert(out, kv.first, kv.second);
+    if (child_keys) {
+        child_keys->resize(keep.size());
+        for (size_t i = 0; i < keep.size(); i++) (*child_keys)[i] = keep[i].first;
+    }
 }

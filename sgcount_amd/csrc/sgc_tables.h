@@ -30,4 +30,8 @@ int sgc_build_library_table(const uint8_t *seqs, uint32_t n, uint32_t L, uint32_
 // two or more parents are dropped.  Only ACGT substitutions are stored; the 'N' children are resolved
 // in-kernel by probing the library (sgc_kernels.hip window_assign).
 void sgc_build_permute_table(const std::vector<uint64_t> &keys, uint32_t L, const sgc_host_table &lib,
-                             sgc_host_table &out);
+                             sgc_host_table &out, std::vector<uint64_t> *child_keys = nullptr);
+
+// Blocked Bloom filter over `keys` with 2^log2_words 64-bit words (sgc_format.h sgc_bloom_*).
+void sgc_build_bloom(const std::vector<uint64_t> &keys, uint32_t log2_words, std::vector<uint64_t> &out);
+uint32_t sgc_bloom_log2_words(uint64_t n_keys, uint32_t bits_per_key, uint32_t min_log2, uint32_t max_log2);
