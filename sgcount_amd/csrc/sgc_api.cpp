@@ -72,6 +72,7 @@ struct sgc_sample {
     unsigned long long *d_matched = nullptr;
     uint64_t total = 0;
     uint64_t since_fold = 0;     // reads counted into d_c32 since the last fold (u32 overflow guard)
+    size_t state_bytes = 0;
 };
 
 // ---- helpers -------------------------------------------------------------------------------------
@@ -88,7 +89,8 @@ static int ensure(void **p, size_t *cap, size_t need) {
 static hipEvent_t ev_get(sgc_ctx *c) {
     if (!c->free_events.empty()) { hipEvent_t e = c->free_events.back(); c->free_events.pop_back(); return e; }
     hipEvent_t e = nullptr;
-    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    // timing markers only: no system-scope fence (a default event makes the L2 write back its dirty lines)
+    if (hipEventCreateWithFlags(&e, hipEventDisableSystemFence) != hipSuccess) return nullptr;
     return e;
 }
 
@@ -407,10 +409,12 @@ int sgc_sample_begin(sgc_ctx *c, sgc_sample **out, int reverse, uint32_t offset,
     sgc_sample *s = new (std::nothrow) sgc_sample();
     if (!s) return fail(SGC_E_OOM, "sgc_sample_begin: out of host memory");
     s->ctx = c; s->reverse = reverse != 0; s->offset = offset; s->recursion = position_recursion != 0;
-    hipError_t e = hipMalloc((void **)&s->d_c32, (size_t)c->n * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_c64, (size_t)c->n * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&s->d_matched, 8);
-    if (e != hipSuccess) { sgc_sample_free(s); return fail(SGC_E_OOM, std::string("sgc_sample_begin: ") + hipGetErrorString(e)); }
+    // one allocation: u64 counts[n] | u64 matched | u64 spare | u32 counts[n]  (one memset resets a sample)
+    s->state_bytes = (size_t)c->n * 8 + 16 + (size_t)c->n * 4;
+    hipError_t e = hipMalloc((void **)&s->d_c64, s->state_bytes);
+    if (e != hipSuccess) { s->d_c64 = nullptr; sgc_sample_free(s); return fail(SGC_E_OOM, std::string("sgc_sample_begin: ") + hipGetErrorString(e)); }
+    s->d_matched = s->d_c64 + c->n;
+    s->d_c32 = (uint32_t *)(s->d_c64 + c->n + 2);
     int rc = sgc_sample_reset(s);
     if (rc) { sgc_sample_free(s); return rc; }
     *out = s;
@@ -421,9 +425,7 @@ int sgc_sample_reset(sgc_sample *s) {
     if (!s) return fail(SGC_E_ARG, "sgc_sample_reset: NULL");
     sgc_ctx *c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemsetAsync(s->d_c32, 0, (size_t)c->n * 4, c->stream));
-    HIP_TRY(hipMemsetAsync(s->d_c64, 0, (size_t)c->n * 8, c->stream));
-    HIP_TRY(hipMemsetAsync(s->d_matched, 0, 8, c->stream));
+    HIP_TRY(hipMemsetAsync(s->d_c64, 0, s->state_bytes, c->stream));
     s->total = 0; s->since_fold = 0;
     return SGC_OK;
 }
@@ -432,9 +434,7 @@ void sgc_sample_free(sgc_sample *s) {
     if (!s) return;
     hipSetDevice(s->ctx->device);
     hipStreamSynchronize(s->ctx->stream);
-    if (s->d_c32) hipFree(s->d_c32);
     if (s->d_c64) hipFree(s->d_c64);
-    if (s->d_matched) hipFree(s->d_matched);
     delete s;
 }
 
@@ -514,11 +514,11 @@ void *sgc_sample_device_counts(sgc_sample *s) { return s ? (void *)s->d_c64 : nu
 int sgc_sample_export_device(sgc_sample *s, uint64_t *d_out) {
     if (!s || !d_out) return fail(SGC_E_ARG, "sgc_sample_export_device: NULL");
     sgc_ctx *c = s->ctx;
-    int rc = sgc_sample_flush(s);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(d_out, s->d_c64, (size_t)c->n * 8, hipMemcpyDeviceToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_out + c->n, &s->total, 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_out + c->n + 1, s->d_matched, 8, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipSetDevice(c->device));
+    // fold + export in one launch: d_out = counts64 (+= counts32) | total | matched
+    sgc_launch_export(c->stream, s->d_c32, s->d_c64, s->d_matched, s->total, c->n, (unsigned long long *)d_out);
+    HIP_TRY(hipGetLastError());
+    s->since_fold = 0;
     return SGC_OK;
 }
 

@@ -23,6 +23,8 @@ void sgc_launch_count_direct(hipStream_t st, const uint64_t *recs, uint64_t n, u
 void sgc_launch_lookup(hipStream_t st, const uint64_t *keys, uint64_t n, const sgc_table_view &lib,
                        const sgc_table_view &perm, int which, bool has_perm, int32_t *out);
 void sgc_launch_fold(hipStream_t st, uint32_t *c32, unsigned long long *c64, uint32_t n);
+void sgc_launch_export(hipStream_t st, uint32_t *c32, unsigned long long *c64, const unsigned long long *matched,
+                       unsigned long long total, uint32_t n, unsigned long long *out);
 void sgc_launch_pack_reads(hipStream_t st, const uint8_t *seqs, const uint64_t *offsets, uint64_t n, uint32_t L,
                            bool rec16, int reverse, uint32_t o, int recursion, uint64_t *recs);
 void sgc_launch_lookup_gids(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, bool rec16,

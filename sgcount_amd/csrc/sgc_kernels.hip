@@ -176,6 +176,16 @@ __global__ void k_fold(uint32_t *__restrict__ c32, unsigned long long *__restric
     if (i < n) { c64[i] += c32[i]; c32[i] = 0; }
 }
 
+// fold and export in one pass: out = counts64 (+= counts32) | total_reads | matched_reads
+__global__ void k_export(uint32_t *__restrict__ c32, unsigned long long *__restrict__ c64,
+                         const unsigned long long *__restrict__ matched, unsigned long long total, uint32_t n,
+                         unsigned long long *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const unsigned long long v = c64[i] + c32[i]; c64[i] = v; c32[i] = 0; out[i] = v; }
+    if (i == n) out[n] = total;
+    if (i == n + 1) out[n + 1] = *matched;
+}
+
 // ------------------------------------------------------------------------------------------------
 // pack kernel, raw read bytes -> records (one read per thread; v0)
 // ------------------------------------------------------------------------------------------------
@@ -260,6 +270,11 @@ void sgc_launch_lookup(hipStream_t st, const uint64_t *keys, uint64_t n, const s
 void sgc_launch_fold(hipStream_t st, uint32_t *c32, unsigned long long *c64, uint32_t n) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_fold, dim3((n + 255) / 256), dim3(256), 0, st, c32, c64, n);
+}
+
+void sgc_launch_export(hipStream_t st, uint32_t *c32, unsigned long long *c64, const unsigned long long *matched,
+                       unsigned long long total, uint32_t n, unsigned long long *out) {
+    hipLaunchKernelGGL(k_export, dim3((n + 2 + 255) / 256), dim3(256), 0, st, c32, c64, matched, total, n, out);
 }
 
 void sgc_launch_pack_reads(hipStream_t st, const uint8_t *seqs, const uint64_t *offsets, uint64_t n, uint32_t L,

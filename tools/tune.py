@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--workload", choices=["1mm", "exact"], default="1mm")
     ap.add_argument("--nocheck", action="store_true")
+    ap.add_argument("--notiming", action="store_true", help="leave the library's per-kernel events off (wall time only)")
     ap.add_argument("--opts", default="", help="extra options k=v,k=v applied to all variants")
     args = ap.parse_args()
     import torch
@@ -40,7 +41,7 @@ def main():
         specs[item] = (int(v), [kv.split("=") for kv in filter(None, opts.split(";"))])
     res = {v: {"lookup": [], "hist": [], "wall": [], "part": [], "miss": []} for v in variants}
     sig = {}
-    wl.dl.timing(True)
+    wl.dl.timing(not args.notiming)
     for r in range(args.rounds + 1):
         for v in variants:
             wl.dl.set_option("variant", specs[v][0])
