@@ -142,15 +142,21 @@ def main():
         dom_ms = sum(parts.values())
         bpr = ALGO_BYTES[args.workload]
         achieved = bpr * reads_timed / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else None
-        traffic = None
+        # HBM bytes per pass from the rocprofv3 PMC passes committed under profiles/ (tools/pmc_traffic.py:
+        # separate --pmc FETCH_SIZE / WRITE_SIZE runs of this command, gfx950 FETCH_SIZE correction calibrated
+        # on k_partition's known byte count); only quoted for the configuration it was collected on
+        traffic, traffic_note = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and args.reads == 100_000_000 and args.guides == 100_000:
             try:
-                traffic = json.load(open(pmc)).get(args.workload)
+                d = json.load(open(pmc)).get(args.workload)
+                traffic = d["hbm_bytes_per_step"]
+                traffic_note = "%.1f HBM B/read measured vs %.0f algorithmic" % (d["bytes_per_read"], ALGO_BYTES[args.workload])
             except Exception:
                 traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
+                           "traffic_note": traffic_note,
                            "kernel": "count pipeline (k_partition + k_count_slices + k_generic + k_resolve_miss + k_hist_segments)",
                            "algorithmic_bytes_per_read": bpr,
                            "kernel_ms_per_step": dom_ms / args.steps, "kernels": kernels}

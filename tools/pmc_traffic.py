@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Turns rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py into profiles/pmc_traffic.json.
+
+    python tools/pmc_traffic.py <fetch_dir_1mm> <write_dir_1mm> <fetch_dir_exact> <write_dir_exact>
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reads exactly half the bytes
+of a wide coalesced streaming read (128-B requests tallied at 64 B); other access widths are uncalibrated, so
+the factor is calibrated here on a kernel of the same run whose fetched byte count is known exactly:
+k_partition reads every 8-byte record once (n_reads x 8 B) and nothing else of size.
+Per-pass traffic = Σ over the count-pipeline kernels of one step.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+PIPE = ("k_partition", "k_count_slices", "k_generic", "k_resolve_miss", "k_hist_segments", "k_export")
+
+
+def per_kernel(d, counter):
+    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != counter:
+            continue
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        acc[name].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}          # mean per dispatch (= per step)
+
+
+def main():
+    out = {}
+    n_reads = 100_000_000
+    for w, fd, wd in (("1mm", sys.argv[1], sys.argv[2]), ("exact", sys.argv[3], sys.argv[4])):
+        fetch, write = per_kernel(fd, "FETCH_SIZE"), per_kernel(wd, "WRITE_SIZE")
+        cal = (n_reads * 8) / (fetch["k_partition"] * 1024.0)      # true bytes / reported bytes for our 8-B/lane stream
+        kern = {}
+        tot = 0.0
+        for k in PIPE:
+            if k not in fetch:
+                continue
+            rb, wb = fetch[k] * 1024.0 * cal, write.get(k, 0.0) * 1024.0
+            kern[k] = {"fetch_bytes_raw": fetch[k] * 1024.0, "fetch_bytes_corrected": rb, "write_bytes": wb}
+            tot += rb + wb
+        out[w] = {"hbm_bytes_per_step": tot, "bytes_per_read": tot / n_reads, "fetch_correction": cal,
+                  "unit": "bytes per 100M-read pass (FETCH_SIZE x correction + WRITE_SIZE)", "kernels": kern}
+    json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
+                                     "pmc_traffic.json"), "w"), indent=1)
+    for w in out:
+        print(w, "%.2f GB per pass, %.1f B/read, fetch correction x%.2f" % (out[w]["hbm_bytes_per_step"] / 1e9,
+                                                                             out[w]["bytes_per_read"], out[w]["fetch_correction"]))
+        for k, v in out[w]["kernels"].items():
+            print("   %-18s fetch %.3f GB (raw %.3f)  write %.3f GB" % (k, v["fetch_bytes_corrected"] / 1e9,
+                                                                          v["fetch_bytes_raw"] / 1e9, v["write_bytes"] / 1e9))
+
+
+if __name__ == "__main__":
+    main()
