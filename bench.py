@@ -69,6 +69,7 @@ def main():
     import torch.distributed as dist
     from sgcount_amd import synth
     from sgcount_amd.workload import DeviceWorkload
+    from sgcount_amd.distributed import all_gather_rows
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -91,7 +92,7 @@ def main():
     def step():
         wl.step()
         if world > 1:
-            dist.all_gather_into_tensor(matrix, wl.export)   # per-sample count matrix over RCCL/xGMI
+            all_gather_rows(wl.export, matrix)   # per-sample count matrix over RCCL/xGMI
 
     def fence():
         torch.cuda.synchronize()

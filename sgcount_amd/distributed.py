@@ -1,0 +1,45 @@
+"""Multi-GPU orchestration of the count path: samples shard across ranks, the per-sample count columns are
+exchanged once with a single collective (RCCL over xGMI on GPUs, gloo on CPU for the tests).
+
+The reference parallelises across samples only (rayon `into_par_iter` over input files,
+src/count.rs:117-136) and collects the Counters in input order; here one process per GPU owns the samples
+`rank, rank + world, ...` and the `[n_samples x (n_guides + 2)]` matrix (counts | total_reads | matched_reads per
+sample) is assembled with one all-reduce of a zero-padded matrix — each entry has exactly one non-zero
+contributor, so the sum is exact in integers.
+"""
+import torch
+import torch.distributed as dist
+
+
+def assign_samples(n_samples: int, world: int, rank: int):
+    """Sample indices owned by `rank` (round-robin, input order preserved inside a rank)."""
+    return list(range(rank, n_samples, world))
+
+
+def gather_count_matrix(local_rows: dict, n_samples: int, row_len: int, device=None, group=None):
+    """local_rows: {sample_index: 1-D int64 tensor of length row_len} for the samples this rank counted.
+    Returns the full [n_samples, row_len] int64 matrix on every rank."""
+    if device is None:
+        device = next(iter(local_rows.values())).device if local_rows else torch.device("cpu")
+    mat = torch.zeros((n_samples, row_len), dtype=torch.int64, device=device)
+    for i, row in local_rows.items():
+        if not 0 <= i < n_samples:
+            raise IndexError("sample index %d out of range" % i)
+        mat[i].copy_(row.to(device=device, dtype=torch.int64))
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(mat, op=dist.ReduceOp.SUM, group=group)
+    return mat
+
+
+def all_gather_rows(row: torch.Tensor, out: torch.Tensor = None, group=None):
+    """The common case "one sample per rank": every rank contributes one row (counts | total | matched) and
+    receives the [world, row_len] matrix with ONE all-gather (RCCL: 0.8 MB per rank at 100k guides, a single
+    hop on the fully connected xGMI mesh).  Single process: returns row[None]."""
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if out is None:
+        out = torch.empty((world, row.numel()), dtype=row.dtype, device=row.device)
+    if world == 1:
+        out[0].copy_(row)
+    else:
+        dist.all_gather_into_tensor(out, row.contiguous(), group=group)
+    return out
