@@ -41,5 +41,5 @@ def all_gather_rows(row: torch.Tensor, out: torch.Tensor = None, group=None):
     if world == 1:
         out[0].copy_(row)
     else:
-        dist.all_gather_into_tensor(out, row.contiguous(), group=group)
+        dist.all_gather_into_tensor(out.view(-1), row.contiguous().view(-1), group=group)
     return out
