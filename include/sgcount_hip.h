@@ -70,6 +70,9 @@ typedef struct {
 
 /* ---- context: device + library tables -------------------------------------------------------- */
 
+/* Number of HIP devices visible to the process (0 if none / no driver). */
+int sgc_device_count(void);
+
 /* Opens `device`, creates the ctx's stream.  Replaces nothing upstream (the reference has no device). */
 int sgc_init(int device, sgc_ctx **out);
 void sgc_free(sgc_ctx *);

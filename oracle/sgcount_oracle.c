@@ -12,6 +12,7 @@
 #include "sgcount_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -568,5 +569,182 @@ int orc_entropy_offset(const uint8_t *lib_buf, size_t lib_len, const uint8_t *re
     if (rc == ORC_OK) rc = orc_positional_entropy(reads_buf, reads_len, subsample, cmp, cap, &n_cmp);
     if (rc == ORC_OK) rc = orc_minimize_mse(ref, n_ref, cmp, n_cmp, reverse, index);
     free(ref); free(cmp);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* utils.rs — generate_sample_names                                          */
+/* ------------------------------------------------------------------------- */
+
+/* Rust str::trim_end_matches(pat): strips the suffix repeatedly */
+static size_t trim_end_matches(const char *s, size_t n, const char *pat) {
+    size_t m = strlen(pat);
+    while (m && n >= m && memcmp(s + n - m, pat, m) == 0) n -= m;
+    return n;
+}
+
+int orc_generate_sample_names(const char *paths, size_t n, char *out, size_t cap, int *fell_back) {
+    /* utils.rs:20-30: basename = split('/').last(); trim ".gz", ".fasta", ".fastq", ".fa", ".fq" in that order */
+    const char **base = (const char **)calloc(n ? n : 1, sizeof(*base));
+    size_t *blen = (size_t *)calloc(n ? n : 1, sizeof(*blen));
+    const char *p = paths;
+    for (size_t i = 0; i < n; i++) {
+        size_t len = strlen(p);
+        const char *slash = NULL;
+        for (size_t k = 0; k < len; k++) if (p[k] == '/') slash = p + k;
+        const char *b = slash ? slash + 1 : p;
+        size_t bl = len - (size_t)(b - p);
+        bl = trim_end_matches(b, bl, ".gz");
+        bl = trim_end_matches(b, bl, ".fasta");
+        bl = trim_end_matches(b, bl, ".fastq");
+        bl = trim_end_matches(b, bl, ".fa");
+        bl = trim_end_matches(b, bl, ".fq");
+        base[i] = b; blen[i] = bl;
+        p += len + 1;
+    }
+    int dup = 0;                                   /* utils.rs:38-43: HashSet size != len */
+    for (size_t i = 0; i < n && !dup; i++)
+        for (size_t j = i + 1; j < n; j++)
+            if (blen[i] == blen[j] && memcmp(base[i], base[j], blen[i]) == 0) { dup = 1; break; }
+    if (fell_back) *fell_back = dup;
+    size_t w = 0;
+    int rc = ORC_OK;
+    for (size_t i = 0; i < n; i++) {
+        char tmp[32];
+        const char *src = base[i]; size_t sl = blen[i];
+        if (dup) { sl = (size_t)snprintf(tmp, sizeof(tmp), "Sample.%zu", i); src = tmp; }   /* utils.rs:32-36 */
+        if (w + sl + 2 > cap) { rc = ORC_E_ARG; break; }
+        if (i) out[w++] = '\n';
+        memcpy(out + w, src, sl); w += sl;
+    }
+    if (rc == ORC_OK) out[w] = 0;
+    free((void *)base); free(blen);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* genemap.rs                                                                 */
+/* ------------------------------------------------------------------------- */
+
+struct orc_genemap {
+    bsmap map;          /* sgrna → index into genes */
+    uint8_t **gene; size_t *gene_len; size_t n, cap;
+};
+
+void orc_genemap_free(orc_genemap *g) {
+    if (!g) return;
+    for (size_t i = 0; i < g->n; i++) free(g->gene[i]);
+    free(g->gene); free(g->gene_len);
+    bsmap_free(&g->map);
+    free(g);
+}
+
+/* genemap.rs:53-72: for_byte_line (terminator \n or \r\n stripped); split at the first tab */
+orc_genemap *orc_genemap_from_text(const uint8_t *buf, size_t len, int *err) {
+    orc_genemap *g = (orc_genemap *)calloc(1, sizeof(*g));
+    bsmap_init(&g->map, 64, 1);
+    *err = ORC_OK;
+    size_t p = 0;
+    while (p < len) {
+        const uint8_t *nl = (const uint8_t *)memchr(buf + p, '\n', len - p);
+        size_t e = nl ? (size_t)(nl - buf) : len, le = e;
+        if (le > p && buf[le - 1] == '\r') le--;
+        const uint8_t *tab = (const uint8_t *)memchr(buf + p, '\t', le - p);
+        if (!tab) { *err = ORC_E_NOTAB; orc_genemap_free(g); return NULL; }
+        size_t gl = (size_t)(tab - (buf + p));
+        const uint8_t *sg = tab + 1; size_t sl = le - (size_t)(sg - buf);
+        int existed;
+        size_t slot = bsmap_entry(&g->map, sg, sl, &existed);
+        if (existed) { *err = ORC_E_DUPKEY; orc_genemap_free(g); return NULL; }
+        if (g->n == g->cap) {
+            g->cap = g->cap ? g->cap * 2 : 256;
+            g->gene = (uint8_t **)realloc(g->gene, g->cap * sizeof(*g->gene));
+            g->gene_len = (size_t *)realloc(g->gene_len, g->cap * sizeof(size_t));
+        }
+        g->gene[g->n] = (uint8_t *)malloc(gl ? gl : 1); memcpy(g->gene[g->n], buf + p, gl);
+        g->gene_len[g->n] = gl;
+        g->map.val[slot] = g->n++;
+        p = e + 1;
+    }
+    return g;
+}
+
+const uint8_t *orc_genemap_get(const orc_genemap *g, const uint8_t *sgrna, size_t n, size_t *gene_len) {
+    size_t s = bsmap_find(&g->map, sgrna, n);
+    if (s == (size_t)-1) return NULL;
+    if (gene_len) *gene_len = g->gene_len[g->map.val[s]];
+    return g->gene[g->map.val[s]];
+}
+
+long orc_genemap_missing(const orc_genemap *g, const orc_library *lib) {
+    for (size_t i = 0; i < lib->n; i++)
+        if (!orc_genemap_get(g, lib->id[i], lib->id_len[i], NULL)) return (long)i;
+    return -1;
+}
+
+/* ------------------------------------------------------------------------- */
+/* results.rs                                                                 */
+/* ------------------------------------------------------------------------- */
+
+int orc_generate_columns(const char *names, size_t n, int with_genemap, char *out, size_t cap) {
+    size_t w = (size_t)snprintf(out, cap, "Guide");                /* results.rs:36 */
+    const char *p = names;
+    for (size_t i = 0; i < n; i++) {
+        if (i == 0 && with_genemap) w += (size_t)snprintf(out + w, w < cap ? cap - w : 0, "\tGene");   /* :37-39 */
+        w += (size_t)snprintf(out + w, w < cap ? cap - w : 0, "\t%s", p);                               /* :40 */
+        p += strlen(p) + 1;
+        if (w >= cap) return ORC_E_ARG;
+    }
+    return ORC_OK;
+}
+
+long orc_format_results(const orc_library *lib, const uint64_t *counts, size_t n_samples, const char *names,
+                        const orc_genemap *genemap, int include_zero, char *out, size_t cap) {
+    /* Counter per sample: results keyed by id (counter.rs:232-235) */
+    bsmap *res = (bsmap *)calloc(n_samples ? n_samples : 1, sizeof(bsmap));
+    for (size_t s = 0; s < n_samples; s++) {
+        bsmap_init(&res[s], lib->n + 16, 0);
+        for (size_t i = 0; i < lib->n; i++) {
+            uint64_t c = counts[s * lib->n + i];
+            if (!c) continue;
+            int existed;
+            size_t slot = bsmap_entry(&res[s], lib->id[i], lib->id_len[i], &existed);
+            res[s].val[slot] += c;
+        }
+    }
+    long rc = 0;
+    if (orc_generate_columns(names, n_samples, genemap != NULL, out, cap) != ORC_OK) { rc = ORC_E_ARG; goto done; }
+    {
+        size_t w = strlen(out);
+        if (w + 2 > cap) { rc = ORC_E_ARG; goto done; }
+        out[w++] = '\n';
+        for (size_t i = 0; i < lib->n; i++) {                      /* results.rs:79 library.values() */
+            size_t row0 = w;
+            uint64_t total = 0;
+            if (w + lib->id_len[i] + 2 > cap) { rc = ORC_E_ARG; goto done; }
+            memcpy(out + w, lib->id[i], lib->id_len[i]); w += lib->id_len[i];
+            for (size_t s = 0; s < n_samples; s++) {
+                if (s == 0 && genemap) {                            /* results.rs:46-62 append_gene */
+                    size_t gl = 0;
+                    const uint8_t *gene = orc_genemap_get(genemap, lib->id[i], lib->id_len[i], &gl);
+                    if (!gene) { rc = ORC_E_NOGENE; goto done; }
+                    if (w + gl + 2 > cap) { rc = ORC_E_ARG; goto done; }
+                    out[w++] = '\t'; memcpy(out + w, gene, gl); w += gl;
+                }
+                size_t slot = bsmap_find(&res[s], lib->id[i], lib->id_len[i]);
+                uint64_t c = slot == (size_t)-1 ? 0 : res[s].val[slot];          /* counter.rs:71-76 */
+                if (w + 24 > cap) { rc = ORC_E_ARG; goto done; }
+                w += (size_t)snprintf(out + w, cap - w, "\t%llu", (unsigned long long)c);   /* results.rs:65-67 */
+                total += c;
+            }
+            if (include_zero || total > 0) out[w++] = '\n';        /* results.rs:90-94 */
+            else w = row0;
+        }
+        out[w] = 0;
+        rc = (long)w;
+    }
+done:
+    for (size_t s = 0; s < n_samples; s++) bsmap_free(&res[s]);
+    free(res);
     return rc;
 }

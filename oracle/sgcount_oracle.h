@@ -107,6 +107,31 @@ int orc_minimize_mse(const double *ref, size_t n_ref, const double *cmp, size_t 
 int orc_entropy_offset(const uint8_t *lib_buf, size_t lib_len, const uint8_t *reads_buf, size_t reads_len,
                        size_t subsample, int *reverse, size_t *index);
 
+/* ---- utils.rs / genemap.rs / results.rs (the callers' side of the path) ---- */
+/* utils.rs:18-49 generate_sample_names.  paths: n NUL-terminated strings back to back; out: names joined by
+ * '\n'.  Returns ORC_OK, or ORC_E_ARG if cap is too small.  *fell_back = 1 if duplicate basenames forced
+ * the "Sample.N" names. */
+int orc_generate_sample_names(const char *paths, size_t n, char *out, size_t cap, int *fell_back);
+
+typedef struct orc_genemap orc_genemap;
+#define ORC_E_NOTAB (-8)        /* genemap.rs:58 panic "Missing '\t' in gene map" */
+#define ORC_E_DUPKEY (-9)       /* genemap.rs:60-64 assert "Duplicate sgRNA key found in gene map" */
+#define ORC_E_NOGENE (-10)      /* results.rs:59 panic "Missing sgrna -> gene mapping" */
+/* genemap.rs:53-72 build() from text */
+orc_genemap *orc_genemap_from_text(const uint8_t *buf, size_t len, int *err);
+void orc_genemap_free(orc_genemap *);
+const uint8_t *orc_genemap_get(const orc_genemap *, const uint8_t *sgrna, size_t n, size_t *gene_len);  /* :76-78 */
+/* genemap.rs:81-86 missing_aliases over library.values() (file order here): index of first missing or -1 */
+long orc_genemap_missing(const orc_genemap *, const orc_library *);
+
+/* results.rs:32-43 generate_columns; names: n NUL-terminated strings back to back */
+int orc_generate_columns(const char *names, size_t n, int with_genemap, char *out, size_t cap);
+/* results.rs:71-99 write_results into a buffer: header line + one line per library alias (file order),
+ * counts[s * n_guides + i] = per-guide counts of sample s (pooled by id like Counter::get_value).
+ * Returns bytes written (excluding NUL), or a negative ORC_E_* code. */
+long orc_format_results(const orc_library *, const uint64_t *counts, size_t n_samples, const char *names,
+                        const orc_genemap *genemap, int include_zero, char *out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,7 @@ class LibInfo(C.Structure):
 # every symbol include/sgcount_hip.h declares: name -> (restype, argtypes)
 _vp, _u8p, _u64, _u32, _i = C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
 SYMBOLS = {
+    "sgc_device_count": (_i, []),
     "sgc_init": (_i, [_i, C.POINTER(_vp)]),
     "sgc_free": (None, [_vp]),
     "sgc_set_stream": (_i, [_vp, _vp]),

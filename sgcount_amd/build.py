@@ -16,6 +16,10 @@ CSRC = os.path.join(PKG, "csrc")
 INC = os.path.join(os.path.dirname(PKG), "include")
 SO = os.path.join(PKG, "libsgcount_hip.so")
 SYNTH_SO = os.path.join(PKG, "libsgcount_synth.so")
+HOST_SO = os.path.join(PKG, "libsgcount_host.so")
+CLI = os.path.join(PKG, "bin", "sgcount-hip")
+HOST_SRCS = [os.path.join("host", f) for f in ("sgh.cpp", "sgh_cli.cpp", "sgh_capi.cpp")]
+HOST_HDRS = [os.path.join("host", "sgh.hpp"), os.path.join(INC, "sgcount_hip.h")]
 
 TARGETS = {
     SO: (["sgc_api.cpp", "sgc_tables.cpp", "sgc_kernels.hip", "sgc_part.hip"],
@@ -55,9 +59,39 @@ def build_one(so, force=False, verbose=False):
     return so
 
 
+def _host_needs_build(out):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    deps = [os.path.join(CSRC, f) for f in HOST_SRCS + HOST_HDRS] + [SO, os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build_host(force=False, verbose=False):
+    """C++ host side (FASTX reader, offsetter, gene map, results, CLI) — plain g++ over the C ABI."""
+    cxx = shutil.which("g++") or "g++"
+    common = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-pthread"]
+    link = ["-L" + PKG, "-lsgcount_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + PKG]
+    srcs = [os.path.join(CSRC, f) for f in HOST_SRCS]
+    if force or _host_needs_build(HOST_SO):
+        cmd = [cxx] + common + ["-shared", "-DSGH_NO_MAIN", "-o", HOST_SO] + srcs + link
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    if force or _host_needs_build(CLI):
+        os.makedirs(os.path.dirname(CLI), exist_ok=True)
+        cmd = [cxx] + common + ["-o", CLI] + srcs[:2] + ["-L" + PKG, "-lsgcount_hip", "-lz", "-Wl,-rpath,$ORIGIN/..",
+                                                         "-Wl,-rpath," + PKG]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return HOST_SO
+
+
 def build(force=False, verbose=False):
     for so in TARGETS:
         build_one(so, force, verbose)
+    build_host(force, verbose)
     return SO
 
 

@@ -1,0 +1,132 @@
+// sgh_capi.cpp — flat C entry points over the C++ host (for the Python tests; libsgcount_host.so).
+// Every function returns 0 on success, 1 for an sgh::Error, 101 for an sgh::Panic (the reference's exit codes)
+// and leaves the message in sgh_last_error().
+#include <cstring>
+#include <string>
+
+#include "sgh.hpp"
+
+static thread_local std::string g_err;
+template <class F> static int guard(F &&f) {
+    try { f(); g_err.clear(); return 0; }
+    catch (const sgh::Panic &e) { g_err = e.what(); return 101; }
+    catch (const std::exception &e) { g_err = e.what(); return 1; }
+}
+static std::vector<std::string> split0(const char *blob, int n) {      // n NUL-terminated strings back to back
+    std::vector<std::string> v;
+    for (int i = 0; i < n; i++) { v.emplace_back(blob); blob += v.back().size() + 1; }
+    return v;
+}
+static int put(const std::string &s, char *out, size_t cap) {
+    if (s.size() + 1 > cap) { g_err = "output buffer too small"; return 1; }
+    memcpy(out, s.c_str(), s.size() + 1);
+    return 0;
+}
+
+extern "C" {
+
+const char *sgh_last_error(void) { return g_err.c_str(); }
+
+int sgh_cli(int argc, char **argv) { return sgh::cli_main(argc, argv); }
+
+// entropy offset of every input (offsetter.rs:185-210): reverse_out[i], index_out[i]
+int sgh_entropy_offset_group(const char *library_path, const char *inputs_blob, int n_inputs, uint64_t subsample,
+                             int *reverse_out, uint64_t *index_out) {
+    return guard([&] {
+        auto offs = sgh::entropy_offset_group(library_path, split0(inputs_blob, n_inputs), (size_t)subsample);
+        for (size_t i = 0; i < offs.size(); i++) { reverse_out[i] = offs[i].reverse; index_out[i] = offs[i].index; }
+    });
+}
+
+int sgh_positional_entropy(const char *path, uint64_t take, double *out, uint64_t cap, uint64_t *n_out) {
+    return guard([&] {
+        sgh::FastxReader rd(path);
+        auto h = sgh::positional_entropy(rd, (size_t)take);
+        if (h.size() > cap) throw sgh::Error("output buffer too small");
+        memcpy(out, h.data(), h.size() * sizeof(double));
+        *n_out = h.size();
+    });
+}
+
+int sgh_minimize_mse(const double *ref, uint64_t n_ref, const double *cmp, uint64_t n_cmp, int *reverse, uint64_t *index) {
+    return guard([&] {
+        auto o = sgh::minimize_mse(std::vector<double>(ref, ref + n_ref), std::vector<double>(cmp, cmp + n_cmp));
+        *reverse = o.reverse; *index = o.index;
+    });
+}
+
+// names joined with '\n'
+int sgh_generate_sample_names(const char *paths_blob, int n, char *out, uint64_t cap) {
+    return guard([&] {
+        auto names = sgh::generate_sample_names(split0(paths_blob, n));
+        std::string s;
+        for (size_t i = 0; i < names.size(); i++) s += (i ? "\n" : "") + names[i];
+        if (put(s, out, cap)) throw sgh::Error(g_err);
+    });
+}
+
+// gene map: parse `text` (or the file at `path` if text is NULL) and look up `sgrna`; found_out = 0/1
+int sgh_genemap_get(const char *path, const char *text, const char *sgrna, char *gene_out, uint64_t cap, int *found_out) {
+    return guard([&] {
+        sgh::GeneMap g = text ? sgh::GeneMap::from_buffer(text) : sgh::GeneMap::from_path(path);
+        const std::string *v = g.get(sgrna);
+        *found_out = v != nullptr;
+        if (v && put(*v, gene_out, cap)) throw sgh::Error(g_err);
+    });
+}
+
+// first library alias (file order) missing from the gene map, or found_out = 0
+int sgh_genemap_missing(const char *genemap_text, const char *library_path, char *alias_out, uint64_t cap, int *found_out) {
+    return guard([&] {
+        sgh::GeneMap g = sgh::GeneMap::from_buffer(genemap_text);
+        sgh::Library lib = sgh::Library::from_path(library_path);
+        const std::string *m = g.missing_alias(lib);
+        *found_out = m != nullptr;
+        if (m && put(*m, alias_out, cap)) throw sgh::Error(g_err);
+    });
+}
+
+int sgh_generate_columns(const char *names_blob, int n, int with_genemap, char *out, uint64_t cap) {
+    return guard([&] {
+        sgh::GeneMap g;
+        if (put(sgh::generate_columns(split0(names_blob, n), with_genemap ? &g : nullptr), out, cap)) throw sgh::Error(g_err);
+    });
+}
+
+// results table from explicit per-sample counts (library order): counts[s * n_guides + i], pooled by id like
+// Counter.  genemap_text may be NULL.
+int sgh_format_results(const char *library_path, const uint64_t *counts, int n_samples, const char *names_blob,
+                       const char *genemap_text, int include_zero, char *out, uint64_t cap) {
+    return guard([&] {
+        sgh::Library lib = sgh::Library::from_path(library_path);
+        std::vector<sgh::SampleCounts> res(n_samples);
+        for (int s = 0; s < n_samples; s++)
+            for (size_t i = 0; i < lib.ids.size(); i++)
+                if (counts[(size_t)s * lib.ids.size() + i]) res[s].by_id[lib.ids[i]] += counts[(size_t)s * lib.ids.size() + i];
+        sgh::GeneMap g;
+        if (genemap_text) g = sgh::GeneMap::from_buffer(genemap_text);
+        if (put(sgh::format_results(res, lib, split0(names_blob, n_samples), genemap_text ? &g : nullptr, include_zero != 0),
+                out, cap))
+            throw sgh::Error(g_err);
+    });
+}
+
+// library facts (library.rs): n records, size; ids joined by '\n'
+int sgh_library_info(const char *path, uint64_t *n_out, uint64_t *size_out) {
+    return guard([&] {
+        sgh::Library lib = sgh::Library::from_path(path);
+        *n_out = lib.seqs.size(); *size_out = lib.size;
+    });
+}
+
+// FASTX reader check: number of records and total sequence bytes
+int sgh_fastx_stats(const char *path, uint64_t *n_records, uint64_t *seq_bytes, uint64_t *id_bytes) {
+    return guard([&] {
+        sgh::FastxReader rd(path);
+        sgh::RecordView r;
+        *n_records = *seq_bytes = *id_bytes = 0;
+        while (rd.next(r)) { (*n_records)++; *seq_bytes += r.seq_len; *id_bytes += r.id_len; }
+    });
+}
+
+}  // extern "C"

@@ -200,6 +200,12 @@ uint32_t sgc_record_bytes(uint32_t L) {
     return L <= SGC_REC8_MAXL ? 8 : 16;
 }
 
+int sgc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
 int sgc_init(int device, sgc_ctx **out) {
     if (!out) return fail(SGC_E_ARG, "sgc_init: out is NULL");
     *out = nullptr;

@@ -1,0 +1,117 @@
+"""ctypes binding of libsgcount_host.so — the C++ host side (FASTX reader, offsetter, gene map, results table,
+sample names, CLI).  Return codes follow the reference's exit codes: 0 ok, 1 error (anyhow), 101 panic."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _ffi, build as _build
+
+
+class HostError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        _ffi.load()                      # libsgcount_hip.so first (shared HIP runtime, DT_NEEDED of the host lib)
+        if _build._host_needs_build(_build.HOST_SO) or _build._host_needs_build(_build.CLI):
+            _build.build_host()
+        L = C.CDLL(_build.HOST_SO)
+        L.sgh_last_error.restype = C.c_char_p
+        for name in ("sgh_cli", "sgh_entropy_offset_group", "sgh_positional_entropy", "sgh_minimize_mse",
+                     "sgh_generate_sample_names", "sgh_genemap_get", "sgh_genemap_missing", "sgh_generate_columns",
+                     "sgh_format_results", "sgh_library_info", "sgh_fastx_stats"):
+            getattr(L, name).restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc:
+        raise HostError(rc, load().sgh_last_error().decode("utf-8", "replace"))
+
+
+def _blob(strings):
+    return b"".join((x if isinstance(x, bytes) else x.encode()) + b"\0" for x in strings)
+
+
+def cli_path():
+    load()
+    return _build.CLI
+
+
+def entropy_offset_group(library_path, inputs, subsample=5000):
+    n = len(inputs)
+    rev = (C.c_int * n)()
+    idx = (C.c_uint64 * n)()
+    _chk(load().sgh_entropy_offset_group(library_path.encode(), _blob(inputs), n, C.c_uint64(subsample), rev, idx))
+    return [(bool(rev[i]), int(idx[i])) for i in range(n)]
+
+
+def positional_entropy(path, take=2 ** 64 - 1):
+    out = (C.c_double * 65536)()
+    n = C.c_uint64(0)
+    _chk(load().sgh_positional_entropy(path.encode(), C.c_uint64(take), out, C.c_uint64(65536), C.byref(n)))
+    return list(out[: n.value])
+
+
+def minimize_mse(ref, cmp):
+    a = (C.c_double * len(ref))(*ref)
+    b = (C.c_double * len(cmp))(*cmp)
+    rev, idx = C.c_int(0), C.c_uint64(0)
+    _chk(load().sgh_minimize_mse(a, C.c_uint64(len(ref)), b, C.c_uint64(len(cmp)), C.byref(rev), C.byref(idx)))
+    return bool(rev.value), int(idx.value)
+
+
+def generate_sample_names(paths):
+    out = C.create_string_buffer(1 << 16)
+    _chk(load().sgh_generate_sample_names(_blob(paths), len(paths), out, C.c_uint64(len(out))))
+    return out.value.decode().split("\n") if paths else []
+
+
+def genemap_get(sgrna, text=None, path=None):
+    out = C.create_string_buffer(1 << 12)
+    found = C.c_int(0)
+    _chk(load().sgh_genemap_get(path.encode() if path else None, text, sgrna, out, C.c_uint64(len(out)), C.byref(found)))
+    return out.value if found.value else None
+
+
+def genemap_missing(genemap_text, library_path):
+    out = C.create_string_buffer(1 << 12)
+    found = C.c_int(0)
+    _chk(load().sgh_genemap_missing(genemap_text, library_path.encode(), out, C.c_uint64(len(out)), C.byref(found)))
+    return out.value if found.value else None
+
+
+def generate_columns(names, with_genemap=False):
+    out = C.create_string_buffer(1 << 16)
+    _chk(load().sgh_generate_columns(_blob(names), len(names), int(with_genemap), out, C.c_uint64(len(out))))
+    return out.value.decode()
+
+
+def format_results(library_path, counts_per_sample, names, genemap_text=None, include_zero=False):
+    flat = np.ascontiguousarray(np.array(counts_per_sample, dtype=np.uint64).reshape(-1))
+    cap = 1 << 24
+    out = C.create_string_buffer(cap)
+    _chk(load().sgh_format_results(library_path.encode(), flat.ctypes.data_as(C.POINTER(C.c_uint64)), len(counts_per_sample),
+                                   _blob(names), genemap_text, int(include_zero), out, C.c_uint64(cap)))
+    return out.value.decode()
+
+
+def library_info(path):
+    n, size = C.c_uint64(0), C.c_uint64(0)
+    _chk(load().sgh_library_info(path.encode(), C.byref(n), C.byref(size)))
+    return n.value, size.value
+
+
+def fastx_stats(path):
+    a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+    _chk(load().sgh_fastx_stats(path.encode(), C.byref(a), C.byref(b), C.byref(c)))
+    return a.value, b.value, c.value

@@ -77,6 +77,19 @@ def lib():
         L.orc_count_text.restype = C.c_int
         L.orc_count_text.argtypes = [u8p, sz, u8p, sz, C.c_int, sz, C.c_int, C.c_int,
                                      C.POINTER(C.c_uint64), sz, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.orc_generate_sample_names.restype = C.c_int
+        L.orc_generate_sample_names.argtypes = [u8p, sz, C.c_char_p, sz, C.POINTER(C.c_int)]
+        L.orc_genemap_from_text.restype = vp
+        L.orc_genemap_from_text.argtypes = [u8p, sz, C.POINTER(C.c_int)]
+        L.orc_genemap_free.argtypes = [vp]
+        L.orc_genemap_get.restype = vp
+        L.orc_genemap_get.argtypes = [vp, u8p, sz, C.POINTER(sz)]
+        L.orc_genemap_missing.restype = C.c_long
+        L.orc_genemap_missing.argtypes = [vp, vp]
+        L.orc_generate_columns.restype = C.c_int
+        L.orc_generate_columns.argtypes = [u8p, sz, C.c_int, C.c_char_p, sz]
+        L.orc_format_results.restype = C.c_long
+        L.orc_format_results.argtypes = [vp, C.POINTER(C.c_uint64), sz, u8p, vp, C.c_int, C.c_char_p, sz]
         L.orc_position_counts.restype = C.c_int
         L.orc_position_counts.argtypes = [u8p, sz, sz, C.POINTER(C.c_double), sz, C.POINTER(sz)]
         L.orc_positional_entropy.restype = C.c_int
@@ -261,3 +274,65 @@ def entropy_offset(lib_text: bytes, reads_text: bytes, subsample=5000):
     if rc:
         raise OracleError(rc)
     return bool(rev.value), idx.value
+
+
+E_NOTAB, E_DUPKEY, E_NOGENE = -8, -9, -10
+
+
+def _blob(strings):
+    return b"".join((x if isinstance(x, bytes) else x.encode()) + b"\0" for x in strings)
+
+
+def generate_sample_names(paths):
+    """utils.rs:18-49 → (names, fell_back_to_Sample_N)"""
+    out = C.create_string_buffer(1 << 16)
+    fb = C.c_int(0)
+    rc = lib().orc_generate_sample_names(_blob(paths), len(paths), out, len(out), C.byref(fb))
+    if rc:
+        raise OracleError(rc)
+    return (out.value.decode().split("\n") if paths else []), bool(fb.value)
+
+
+class GeneMap:
+    """genemap.rs GeneMap built from text."""
+
+    def __init__(self, text: bytes):
+        err = C.c_int(0)
+        self.h = lib().orc_genemap_from_text(text, len(text), C.byref(err))
+        if not self.h:
+            raise OracleError(err.value)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_genemap_free(self.h)
+            self.h = None
+
+    def get(self, sgrna: bytes):
+        n = C.c_size_t(0)
+        p = lib().orc_genemap_get(self.h, sgrna, len(sgrna), C.byref(n))
+        return C.string_at(p, n.value) if p else None
+
+    def missing_aliases(self, library: Library):
+        i = lib().orc_genemap_missing(self.h, library.h)
+        return None if i < 0 else library.ids()[i]
+
+
+def generate_columns(names, with_genemap=False):
+    out = C.create_string_buffer(1 << 16)
+    rc = lib().orc_generate_columns(_blob(names), len(names), int(with_genemap), out, len(out))
+    if rc:
+        raise OracleError(rc)
+    return out.value.decode()
+
+
+def format_results(library: Library, counts_per_sample, names, genemap: GeneMap = None, include_zero=False):
+    """results.rs write_results → text.  counts_per_sample: list of per-guide count lists (library order)."""
+    n = library.n()
+    flat = (C.c_uint64 * (n * len(counts_per_sample)))(*[c for row in counts_per_sample for c in row])
+    cap = 64 + (n + 2) * (64 + 24 * max(1, len(counts_per_sample))) + sum(len(x) + 2 for x in names)
+    out = C.create_string_buffer(cap)
+    rc = lib().orc_format_results(library.h, flat, len(counts_per_sample), _blob(names), genemap.h if genemap else None,
+                                  int(include_zero), out, cap)
+    if rc < 0:
+        raise OracleError(rc)
+    return out.raw[:rc].decode()

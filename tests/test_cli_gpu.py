@@ -1,0 +1,116 @@
+"""End-to-end: the `sgcount-hip` command line (C++ host over the C ABI, GPU count path) against tables built by
+the CPU oracle.  Row order is library-file order on both sides, so the comparison is byte for byte."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+import _oracle as O
+from conftest import DATA
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ["sequence", "zero.sequence", "diff.sequence", "offset", "offset_clipped"]
+LIB = os.path.join(DATA, "library.fasta.gz")
+
+
+@pytest.fixture(scope="module")
+def cli():
+    from sgcount_amd import hostlib
+    return hostlib.cli_path()
+
+
+def run(cli, *args):
+    p = subprocess.run([cli, *args], capture_output=True, timeout=300)
+    return p.returncode, p.stdout.decode(), p.stderr.decode()
+
+
+def oracle_table(lib_text, reads_texts, names, offsets, exact, recursion, genemap_text=None, include_zero=False):
+    lib = O.Library(lib_text)
+    cols = []
+    for text, (rev, idx) in zip(reads_texts, offsets):
+        c, _, _ = O.count_text(lib_text, text, rev, idx, exact, recursion)
+        per_guide_pooled = c       # count_text already reports get_value(id) per guide (pooled)
+        cols.append(per_guide_pooled)
+    # format_results pools by id itself, so hand it un-pooled per-guide counts: rebuild them from one Counter
+    cols = []
+    for text, (rev, idx) in zip(reads_texts, offsets):
+        perm = None if exact else O.Permuter(lib)
+        ctr = O.Counter(lib, perm, rev, idx, lib.size(), recursion).feed_text(text)
+        seen, row = set(), []
+        for ident in lib.ids():
+            row.append(0 if ident in seen else ctr.get_value(ident))
+            seen.add(ident)
+        cols.append(row)
+    return O.format_results(lib, cols, names, O.GeneMap(genemap_text) if genemap_text else None, include_zero)
+
+
+def test_single_sample_fixed_offset_exact(cli, example_library_text, example_reads):
+    rc, out, err = run(cli, "-l", LIB, "-i", os.path.join(DATA, "sequence.fastq.gz"), "-a", "5", "-x", "-q")
+    assert rc == 0, err
+    assert out == oracle_table(example_library_text, [example_reads["sequence"]], ["sequence"], [(False, 5)], True, True)
+    assert err == ""
+
+
+@pytest.mark.parametrize("pack", ["device", "host"])
+def test_all_samples_auto_offset_genemap_zero(cli, pack, tmp_path, example_library_text, example_reads):
+    paths = [os.path.join(DATA, n + ".fastq.gz") for n in NAMES]
+    g2s = os.path.join(DATA, "g2s.txt")
+    outp = os.path.join(str(tmp_path), "out.tsv")
+    rc, out, err = run(cli, "-l", LIB, "-i", *paths, "-g", g2s, "-z", "-t", "3", "-o", outp, "--pack", pack)
+    assert rc == 0, err
+    want = oracle_table(example_library_text, [example_reads[n] for n in NAMES], NAMES, [(False, 5)] * 5, False, True,
+                        open(g2s, "rb").read(), True)
+    assert open(outp).read() == want and out == ""
+    assert "Calculated Offsets: [Forward(5), Forward(5), Forward(5), Forward(5), Forward(5)]" in err
+    assert "Finished: offset_clipped; Fraction mapped: 0.999 [999 / 1000]" in err        # count.rs:34-43
+    assert "Finished: diff.sequence; Fraction mapped: 0.908 [1000 / 1101]" in err
+    # without -z the zero rows of zero.sequence only disappear if every sample is zero: none here
+    rc, out2, _ = run(cli, "-l", LIB, "-i", os.path.join(DATA, "zero.sequence.fastq.gz"), "-a", "5", "-q")
+    assert rc == 0 and out2.count("\n") == 1 + 90
+    assert out2 == oracle_table(example_library_text, [example_reads["zero.sequence"]], ["zero.sequence"], [(False, 5)],
+                                False, True)
+
+
+def test_flags_p_r_n(cli, tmp_path, example_library_text, example_reads):
+    # -p: no position recursion; -n names; reverse-complemented input with -r
+    fwd = example_reads["offset_clipped"]
+    lines = fwd.split(b"\n")
+    rc_lines = []
+    for i in range(0, len(lines) - 1, 4):
+        seq = bytes((c ^ 4) if (c & 2) else (c ^ 21) for c in reversed(lines[i + 1]))
+        rc_lines += [lines[i], seq, b"+", lines[i + 3][::-1]]
+    rc_text = b"\n".join(rc_lines) + b"\n"
+    rp = os.path.join(str(tmp_path), "rc.fastq.gz")
+    with gzip.open(rp, "wb") as f:
+        f.write(rc_text)
+    code, out, err = run(cli, "-l", LIB, "-i", rp, os.path.join(DATA, "offset_clipped.fastq.gz"), "-a", "5", "-r", "-p", "-q",
+                         "-n", "revcomp", "forward_read_as_reverse")
+    assert code == 0, err
+    want = oracle_table(example_library_text, [rc_text, fwd], ["revcomp", "forward_read_as_reverse"], [(True, 5), (True, 5)],
+                        False, False)
+    assert out == want
+    assert out.count("\n") > 50                       # the rc sample really matches
+
+
+def test_error_paths(cli, tmp_path):
+    seq = os.path.join(DATA, "sequence.fastq.gz")
+    code, _, err = run(cli, "-l", LIB, "-i", os.path.join(str(tmp_path), "nope.fq"), "-a", "5")
+    assert code == 101 and "Provided filepath does not exist" in err                 # main.rs:130-140
+    code, _, err = run(cli, "-l", LIB, "-i", seq, "-n", "a", "b", "-a", "5")
+    assert code == 101 and "Must provide as many sample names as there are input files" in err    # main.rs:156
+    long_lib = os.path.join(str(tmp_path), "long.fa")
+    open(long_lib, "wb").write(b">a\n" + b"ACGT" * 30 + b"\n")
+    code, _, err = run(cli, "-l", long_lib, "-i", seq, "-a", "5", "-q")
+    assert code == 1 and "Sequences in reference library are larger than the sequences in input." in err   # count.rs:98-100
+    gm = os.path.join(str(tmp_path), "gm.txt")
+    open(gm, "wb").write(b"gene.0\tlib.0\n")
+    code, _, err = run(cli, "-l", LIB, "-i", seq, "-a", "5", "-g", gm, "-q")
+    assert code == 1 and "Missing sgRNA aliases in gene map: \"lib.1\"" in err        # count.rs:90-95 (first in file order)
+    n_lib = os.path.join(str(tmp_path), "n.fa")
+    open(n_lib, "wb").write(b">a\nACGTNCGTACGTACGTACGT\n")
+    code, _, err = run(cli, "-l", n_lib, "-i", seq, "-a", "5", "-q")
+    assert code == 1 and "outside ACGT" in err                                        # no CPU fallback: fails loudly
+    code, out, _ = run(cli, "--help")
+    assert code == 0 and "--library-path" in out and "--no-position-recursion" in out

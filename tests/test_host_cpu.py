@@ -1,0 +1,168 @@
+"""The C++ host side (libsgcount_host.so: FASTX reader, offsetter, gene map, results table, sample names)
+against the CPU oracle and the reference's known answers.  No GPU needed: nothing here counts reads."""
+import gzip
+import os
+import random
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from conftest import DATA
+
+
+@pytest.fixture(scope="module")
+def H():
+    from sgcount_amd import hostlib
+    hostlib.load()
+    return hostlib
+
+
+def _write(tmp_path, name, data: bytes, gz=False):
+    p = os.path.join(str(tmp_path), name)
+    with (gzip.open(p, "wb") if gz else open(p, "wb")) as f:
+        f.write(data)
+    return p
+
+
+def test_fastx_reader_gz_and_plain(H, tmp_path, example_reads, example_library_text):
+    for name, text in example_reads.items():
+        want = (text.count(b"\n") // 4, sum(len(l) for l in text.split(b"\n")[1::4]))
+        assert H.fastx_stats(os.path.join(DATA, name + ".fastq.gz"))[:2] == want
+        assert H.fastx_stats(_write(tmp_path, name + ".fastq", text))[:2] == want
+    assert H.library_info(os.path.join(DATA, "library.fasta.gz")) == (100, 20)
+    # records far larger than the reader's refill granularity, and a last record without a newline
+    big = b">a\n" + b"ACGT" * 3_000_000 + b"\n>b\n" + b"TTGCA" * 1_000_000
+    assert H.fastx_stats(_write(tmp_path, "big.fa", big)) == (2, 12_000_000 + 5_000_000, 2)
+    assert H.fastx_stats(_write(tmp_path, "big.fa.gz", big, gz=True)) == (2, 17_000_000, 2)
+
+
+def test_library_errors(H, tmp_path):
+    with pytest.raises(H.HostError) as e:                   # library.rs:133-136 duplicates ⇒ panic
+        H.library_info(_write(tmp_path, "dup.fa", b">seq.0\nACTG\n>seq.1\nACTG\n"))
+    assert e.value.code == 101 and "duplicate" in str(e.value)
+    with pytest.raises(H.HostError) as e:                   # library.rs:83
+        H.library_info(_write(tmp_path, "bad.fa", b">a\nACTG\n>b\nACT\n"))
+    assert e.value.code == 1 and str(e.value) == "Library sequence sizes are inconsistent"
+    with pytest.raises(H.HostError) as e:
+        H.library_info(_write(tmp_path, "empty.fa", b""))
+    assert e.value.code == 101
+
+
+# ---- offsetter (src/offsetter.rs KATs and oracle agreement) ----------------------------------------
+READER = b">seq.0\nACT\n>seq.1\nACC\n>seq.2\nACT\n"
+OFFSET_READER = b">seq.0\nAACAAACT\n>seq.1\nAACAAACC\n>seq.2\nAACAAACT\n"
+RC_OFFSET_READER = b">seq.0\nAGTTTGTT\n>seq.1\nGGTTTGTT\n>seq.2\nAGTTTGTT\n"
+
+
+def test_offsetter_kats(H, tmp_path):
+    """offsetter.rs:249-328"""
+    assert H.minimize_mse(list(np.linspace(0., 10., 11)), list(np.linspace(10., 20., 100))) == (False, 0)
+    with pytest.raises(H.HostError) as e:
+        H.minimize_mse(list(np.linspace(0., 10., 11)), list(np.linspace(10., 20., 5)))
+    assert e.value.code == 1 and str(e.value).startswith("Sequences in reference library are larger")
+    lib = _write(tmp_path, "r.fa", READER)
+    assert H.entropy_offset_group(lib, [_write(tmp_path, "o.fa", OFFSET_READER)]) == [(False, 5)]
+    assert H.entropy_offset_group(lib, [_write(tmp_path, "rc.fa", RC_OFFSET_READER)]) == [(True, 5)]
+    assert H.positional_entropy(lib) == O.positional_entropy(READER)
+
+
+def test_offsetter_examples_match_oracle(H, example_library_text, example_reads):
+    lib = os.path.join(DATA, "library.fasta.gz")
+    paths = [os.path.join(DATA, n + ".fastq.gz") for n in example_reads]
+    got = H.entropy_offset_group(lib, paths)
+    assert got == [O.entropy_offset(example_library_text, t) for t in example_reads.values()] == [(False, 5)] * 5
+    for n, t in example_reads.items():     # bit-identical f64 entropies (same sequential sums)
+        assert H.positional_entropy(os.path.join(DATA, n + ".fastq.gz"), 5000) == O.positional_entropy(t, 5000)
+
+
+def test_offsetter_random_vs_oracle(H, tmp_path):
+    rng = random.Random(11)
+    for case in range(12):
+        L, pre = rng.choice([8, 12, 20]), rng.randrange(0, 12)
+        guides = [bytes(rng.choice(b"ACGT") for _ in range(L)) for _ in range(60)]
+        lib_text = b"".join(b">g%d\n%s\n" % (i, g) for i, g in enumerate(guides))
+        prefix = bytes(rng.choice(b"ACGT") for _ in range(pre))
+        tail = bytes(rng.choice(b"ACGT") for _ in range(rng.randrange(5, 25)))
+        reads = []
+        for i in range(400):
+            r = prefix + rng.choice(guides) + tail
+            if rng.random() < 0.05:
+                r = r[:rng.randrange(1, len(r))]
+            if rng.random() < 0.1:
+                k = rng.randrange(len(r)); r = r[:k] + b"N" + r[k + 1:]
+            if case % 3 == 2:
+                r = bytes((c ^ 4) if (c & 2) else (c ^ 21) for c in reversed(r))
+            reads.append(r)
+        txt = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)) for i, r in enumerate(reads))
+        lp, rp = _write(tmp_path, "l%d.fa" % case, lib_text), _write(tmp_path, "r%d.fq.gz" % case, txt, gz=True)
+        for sub in (5000, 37):
+            assert H.entropy_offset_group(lp, [rp], sub) == [O.entropy_offset(lib_text, txt, sub)]
+
+
+def test_offsetter_errors(H, tmp_path):
+    lib = _write(tmp_path, "r.fa", b">a\nACGTACGT\n>b\nACGTTTTT\n>c\nAAGTTTTT\n")
+    short = _write(tmp_path, "s.fa", b">r\nACG\n>r\nACG\n>r\nACG\n")
+    with pytest.raises(H.HostError) as e:                    # offsetter.rs:205 wraps :154-156
+        H.entropy_offset_group(lib, [short])
+    assert e.value.code == 1 and str(e.value).startswith("Error in entropy offset calculation:\n\nSequences in reference")
+    with pytest.raises(H.HostError) as e:                    # offsetter.rs:38 expect("empty reader")
+        H.entropy_offset_group(lib, [_write(tmp_path, "e.fa", b"")])
+    assert e.value.code == 101
+    with pytest.raises(H.HostError) as e:                    # offsetter.rs:195 panic
+        H.entropy_offset_group(lib, [os.path.join(str(tmp_path), "nope.fq")])
+    assert e.value.code == 101 and "Unable to open file" in str(e.value)
+
+
+# ---- utils / genemap / results ---------------------------------------------------------------------------
+def test_sample_names_match_oracle_and_kats(H):
+    kat = ["example/some_name_1.fastq.gz", "example/some_name_2.fastq", "example/some_name_3.fasta.gz",
+           "example/some_name_4.fasta", "example/some_name_5.fq.gz", "example/some_name_6.fq",
+           "example/some_name_7.fa.gz", "example/some_name_8.fa"]
+    assert H.generate_sample_names(kat) == ["some_name_%d" % i for i in range(1, 9)]             # utils.rs:55-81
+    dup = ["example/some_name_1.fastq.gz", "example/some_name_1.fastq"] + kat[2:]
+    assert H.generate_sample_names(dup) == ["Sample.%d" % i for i in range(8)]                   # utils.rs:84-104
+    odd = ["a.fq.gz.gz", "/x/y/b.fasta.fa", "c.fastq.fq", "noext", "d.gz.fq", "dir.fq/e.fa", "f.fa.fa.gz"]
+    assert H.generate_sample_names(odd) == O.generate_sample_names(odd)[0] == ["a", "b.fasta", "c.fastq", "noext", "d.gz", "e", "f"]
+
+
+def test_genemap_matches_oracle_and_kats(H, tmp_path):
+    text = b"gene1\tsgrna1\ngene2\tsgrna2\ngene3\tsgrna3\n"
+    for k in (b"sgrna1", b"sgrna3", b"sgrna9"):
+        assert H.genemap_get(k, text=text) == O.GeneMap(text).get(k)
+    g2s = os.path.join(DATA, "g2s.txt")
+    assert H.genemap_get(b"lib.0", path=g2s) == b"gene.0" and H.genemap_get(b"lib.99", path=g2s) == b"gene.9"   # genemap.rs:151-156
+    ok = _write(tmp_path, "ok.fa", b">sgrna1\nACTG\n>sgrna2\ngtca\n>sgrna3\nTCAG\n")
+    bad = _write(tmp_path, "bad.fa", b">sgrna1\nACTG\n>sgrna4\ngtca\n")
+    assert H.genemap_missing(text, ok) is None and H.genemap_missing(text, bad) == b"sgrna4"     # genemap.rs:133-148
+    with pytest.raises(H.HostError) as e:
+        H.genemap_get(b"x", text=b"gene1 sgrna1\n")
+    assert e.value.code == 101 and "Missing" in str(e.value)
+    with pytest.raises(H.HostError) as e:
+        H.genemap_get(b"x", text=b"g\ts\nh\ts\n")
+    assert e.value.code == 101 and str(e.value) == "Duplicate sgRNA key found in gene map: s"
+    with pytest.raises(H.HostError) as e:
+        H.genemap_get(b"x", path=os.path.join(str(tmp_path), "missing.txt"))
+    assert e.value.code == 1 and str(e.value).startswith("Provided gene mapping path doesn't exist")
+    assert H.genemap_get(b"s", text=b"g\ts\r\n") == b"g"
+
+
+def test_results_match_oracle(H, tmp_path):
+    assert H.generate_columns(["A", "B"]) == "Guide\tA\tB"                                          # results.rs:134-139
+    assert H.generate_columns(["A", "B"], True) == "Guide\tGene\tA\tB" == O.generate_columns(["A", "B"], True)
+    rng = random.Random(3)
+    lib_text = gzip.open(os.path.join(DATA, "library.fasta.gz")).read()
+    lib_text += b">lib.0\n" + b"A" * 20 + b"\n"            # a duplicated id: both rows print the pooled count
+    lp = _write(tmp_path, "lib.fa", lib_text)
+    olib = O.Library(lib_text)
+    gm_text = open(os.path.join(DATA, "g2s.txt"), "rb").read()
+    for n_samples in (1, 3):
+        counts = [[rng.choice([0, 0, 1, 7, 123456789012]) for _ in range(101)] for _ in range(n_samples)]
+        names = ["s%d" % i for i in range(n_samples)]
+        for gm in (None, gm_text):
+            for z in (False, True):
+                want = O.format_results(olib, counts, names, O.GeneMap(gm) if gm else None, z)
+                assert H.format_results(lp, counts, names, gm, z) == want
+    with pytest.raises(H.HostError) as e:                                                            # results.rs:59
+        H.format_results(lp, [[1] * 101], ["s"], b"gene.0\tlib.0\n", True)
+    assert e.value.code == 101

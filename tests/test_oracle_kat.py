@@ -212,3 +212,89 @@ def test_offsetter_subsample_take():
     assert O.position_counts(READER_N, take=3) == [[2.0, 0, 0, 0], [0, 2.0, 0, 0], [0, 1.0, 0, 1.0]]
     with pytest.raises(O.OracleError):
         O.position_counts(READER_N, take=0)
+
+
+# ---- results.rs ----
+RES_LIB = b">sgrna1\nACTG\n>sgrna2\nGTCA\n"
+RES_GENEMAP = b"GENE1\tsgrna1\nGENE2\tsgrna2\n"
+
+
+def test_results_generate_columns():
+    """results.rs:134-139"""
+    assert O.generate_columns(["A", "B"]) == "Guide\tA\tB"
+    assert O.generate_columns(["A", "B"], with_genemap=True) == "Guide\tGene\tA\tB"
+
+
+def test_results_append_count_and_gene():
+    """results.rs:164-177: a count cell is "\t100", a gene cell "\tGENE1"; rows = alias[\tgene]\tc1\tc2"""
+    lib = O.Library(RES_LIB)
+    gm = O.GeneMap(RES_GENEMAP)
+    text = O.format_results(lib, [[100, 200], [100, 200]], ["sample1", "sample2"], gm, include_zero=True)
+    assert text == "Guide\tGene\tsample1\tsample2\nsgrna1\tGENE1\t100\t100\nsgrna2\tGENE2\t200\t200\n"
+    text = O.format_results(lib, [[100, 0], [0, 0]], ["s1", "s2"], None, include_zero=False)    # results.rs:90-94
+    assert text == "Guide\ts1\ts2\nsgrna1\t100\t0\n"
+    text = O.format_results(lib, [[100, 0], [0, 0]], ["s1", "s2"], None, include_zero=True)
+    assert text == "Guide\ts1\ts2\nsgrna1\t100\t0\nsgrna2\t0\t0\n"
+
+
+def test_results_missing_gene_panics():
+    """results.rs:59"""
+    lib = O.Library(RES_LIB)
+    with pytest.raises(O.OracleError) as e:
+        O.format_results(lib, [[1, 1]], ["s"], O.GeneMap(b"GENE1\tsgrna1\n"), True)
+    assert e.value.code == O.E_NOGENE
+
+
+# ---- genemap.rs ----
+GM_TEXT = b"gene1\tsgrna1\ngene2\tsgrna2\ngene3\tsgrna3\n"
+
+
+def test_genemap_build():
+    """genemap.rs:124-130"""
+    g = O.GeneMap(GM_TEXT)
+    assert (g.get(b"sgrna1"), g.get(b"sgrna2"), g.get(b"sgrna3")) == (b"gene1", b"gene2", b"gene3")
+    assert g.get(b"sgrna4") is None
+
+
+def test_genemap_validate_library():
+    """genemap.rs:133-148 (library sequences may be any bytes, e.g. lowercase)"""
+    g = O.GeneMap(GM_TEXT)
+    assert g.missing_aliases(O.Library(b">sgrna1\nACTG\n>sgrna2\ngtca\n>sgrna3\nTCAG\n")) is None
+    assert g.missing_aliases(O.Library(b">sgrna1\nACTG\n>sgrna4\ngtca\n")) == b"sgrna4"
+
+
+def test_genemap_from_file():
+    """genemap.rs:151-156 example/g2s.txt"""
+    import os
+    from conftest import DATA
+    g = O.GeneMap(open(os.path.join(DATA, "g2s.txt"), "rb").read())
+    assert g.get(b"lib.0") == b"gene.0" and g.get(b"lib.99") == b"gene.9"
+
+
+def test_genemap_errors():
+    """genemap.rs:58 missing tab; :60-64 duplicate sgRNA"""
+    with pytest.raises(O.OracleError) as e:
+        O.GeneMap(b"gene1 sgrna1\n")
+    assert e.value.code == O.E_NOTAB
+    with pytest.raises(O.OracleError) as e:
+        O.GeneMap(b"gene1\tsgrna1\ngene2\tsgrna1\n")
+    assert e.value.code == O.E_DUPKEY
+
+
+# ---- utils.rs ----
+def test_utils_sample_names():
+    """utils.rs:55-81"""
+    paths = ["example/some_name_1.fastq.gz", "example/some_name_2.fastq", "example/some_name_3.fasta.gz",
+             "example/some_name_4.fasta", "example/some_name_5.fq.gz", "example/some_name_6.fq",
+             "example/some_name_7.fa.gz", "example/some_name_8.fa"]
+    names, fb = O.generate_sample_names(paths)
+    assert names == ["some_name_%d" % i for i in range(1, 9)] and not fb
+
+
+def test_utils_sample_names_duplicates():
+    """utils.rs:84-104"""
+    paths = ["example/some_name_1.fastq.gz", "example/some_name_1.fastq", "example/some_name_3.fasta.gz",
+             "example/some_name_4.fasta", "example/some_name_5.fq.gz", "example/some_name_6.fq",
+             "example/some_name_7.fa.gz", "example/some_name_8.fa"]
+    names, fb = O.generate_sample_names(paths)
+    assert names == ["Sample.%d" % i for i in range(8)] and fb
