@@ -150,6 +150,11 @@ int sgc_sample_export_device(sgc_sample *, uint64_t *d_out);
 int sgc_sample_reset(sgc_sample *);
 void sgc_sample_free(sgc_sample *);
 
+/* Page-locked host buffers for the push_* entry points (pageable memory works too, through a slower staging
+ * copy inside the HIP runtime). */
+void *sgc_alloc_pinned(size_t bytes);
+void sgc_free_pinned(void *p);
+
 /* Tuning knobs ("variant": count-kernel variant). */
 int sgc_set_option(sgc_ctx *, const char *key, int64_t value);
 

@@ -54,6 +54,8 @@ SYMBOLS = {
     "sgc_sample_export_device": (_i, [_vp, _vp]),
     "sgc_sample_reset": (_i, [_vp]),
     "sgc_sample_free": (None, [_vp]),
+    "sgc_alloc_pinned": (_vp, [C.c_size_t]),
+    "sgc_free_pinned": (None, [_vp]),
     "sgc_set_option": (_i, [_vp, C.c_char_p, C.c_int64]),
     "sgc_timing_enable": (_i, [_vp, _i]),
     "sgc_timing_read": (_i, [_vp, C.POINTER(Timing), _i]),

@@ -332,12 +332,69 @@ static void sgc_check(int rc, const char *what) {
     }
 }
 
+// FASTQ at speed (replaces fxread for the count loop): the host only inflates/reads text and cuts it at record
+// boundaries by counting newlines; record boundaries inside a chunk, window extraction and packing happen on
+// the GPU (sgc_sample_push_fastq).  Two pinned buffers alternate so that reading chunk k+1 overlaps counting k.
+static bool count_fastq_text(sgc_sample *smp, const std::string &path, const CountOptions &opt) {
+    gzFile f = gzopen(path.c_str(), "rb");
+    if (!f) throw Error("No such file or directory (os error 2): " + path);
+    struct FGuard { gzFile f; ~FGuard() { gzclose(f); } } fg{f};
+    gzbuffer(f, 1u << 20);
+    const int first = gzgetc(f);
+    if (first != '@') return false;                      // not FASTQ: the caller uses the record reader
+    gzungetc(first, f);
+    const size_t cap = std::max<size_t>(opt.chunk_bytes, 1u << 16);
+    uint8_t *buf[2] = {(uint8_t *)sgc_alloc_pinned(cap), (uint8_t *)sgc_alloc_pinned(cap)};
+    struct BGuard { uint8_t **b; ~BGuard() { sgc_free_pinned(b[0]); sgc_free_pinned(b[1]); } } bg{buf};
+    if (!buf[0] || !buf[1]) throw Error("cannot allocate pinned host buffers");
+    size_t have = 0;                                     // bytes carried over (an incomplete record)
+    int cur = 0;
+    bool eof = false;
+    while (!eof || have) {
+        while (have < cap && !eof) {
+            const int got = gzread(f, buf[cur] + have, (unsigned)std::min<size_t>(cap - have, 1u << 30));
+            if (got < 0) throw Error("read error in " + path);
+            if (got == 0) eof = true;
+            have += (size_t)got;
+        }
+        // cut after the last newline that completes a whole number of 4-line records
+        size_t lines = 0, cut = 0;
+        const uint8_t *p = buf[cur], *end = buf[cur] + have;
+        while (p < end) {
+            const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
+            if (!nl) break;
+            lines++;
+            p = nl + 1;
+            if ((lines & 3) == 0) cut = (size_t)(p - buf[cur]);
+        }
+        if (eof) {                                       // final chunk: an unterminated last line is allowed
+            const size_t tail_lines = lines + (have && buf[cur][have - 1] != '\n' ? 1 : 0);
+            if (tail_lines % 4 != 0) throw Panic("truncated FASTQ record in " + path);
+            cut = have;
+        } else if (cut == 0) {
+            throw Error("FASTQ record larger than the text chunk in " + path);
+        }
+        if (cut) {
+            sgc_check(sgc_sample_sync(smp), "sgc_sample_sync");          // the other buffer's count pass may still be running
+            sgc_check(sgc_sample_push_fastq(smp, buf[cur], cut, SGC_MEM_HOST, nullptr), "sgc_sample_push_fastq");
+        }
+        const size_t rest = have - cut;
+        memcpy(buf[cur ^ 1], buf[cur] + cut, rest);
+        have = rest;
+        cur ^= 1;
+        if (eof && !have) break;
+    }
+    return true;
+}
+
 static SampleCounts count_sample(sgc_ctx *ctx, const std::string &path, const Offset &off, const Library &library,
                                  const CountOptions &opt) {
-    FastxReader reader(path);                                                         // count.rs:24
     sgc_sample *smp = nullptr;
     sgc_check(sgc_sample_begin(ctx, &smp, off.reverse, (uint32_t)off.index, opt.position_recursion), "sgc_sample_begin");
     struct Guard { sgc_sample *s; ~Guard() { sgc_sample_free(s); } } guard{smp};
+    const bool parsed_on_device = opt.device_parse && opt.device_pack && count_fastq_text(smp, path, opt);
+    if (!parsed_on_device) {
+    FastxReader reader(path);                                                         // count.rs:24
     const uint32_t L = (uint32_t)library.size;
     const size_t words = sgc_record_bytes(L) / 8;
     std::vector<uint8_t> bytes;
@@ -364,6 +421,7 @@ static SampleCounts count_sample(sgc_ctx *ctx, const std::string &path, const Of
         if (offsets.size() > opt.batch_reads) flush();
     }
     flush();
+    }
     std::vector<uint64_t> counts(library.seqs.size());
     SampleCounts out;
     sgc_check(sgc_sample_finish(smp, counts.data(), &out.total_reads, &out.matched_reads), "sgc_sample_finish");

@@ -88,6 +88,8 @@ struct CountOptions {
     const GeneMap *genemap = nullptr;
     size_t threads = 1;
     bool device_pack = true;             // raw bytes → records on the GPU (else sgc_pack_reads_host)
+    bool device_parse = true;            // FASTQ inputs: ship text chunks, find record boundaries on the GPU
+    size_t chunk_bytes = 64u << 20;      // text chunk size for device_parse
     size_t batch_reads = 1u << 20;
 };
 void count(const CountOptions &opt);                     // count.rs:74-148

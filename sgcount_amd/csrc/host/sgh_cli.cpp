@@ -26,7 +26,8 @@ static const char *USAGE =
     "  -t, --threads <THREADS>               Number of Threads to Use for Parallel Jobs [default: 1]\n"
     "  -q, --quiet                           Does not show progress\n"
     "  -z, --include-zero                    Include zero count sgRNAs in output table\n"
-    "      --pack <host|device>              Where reads are 2-bit packed [default: device]\n"
+    "      --pack <host|device|fastq>        Where reads are parsed/packed: host packer, GPU packer on host-parsed reads,\n"
+    "                                        or FASTQ text parsed on the GPU [default: fastq]\n"
     "  -h, --help                            Print help\n"
     "  -V, --version                         Print version\n";
 
@@ -68,7 +69,12 @@ int cli_main(int argc, char **argv) {
             else if (a == "-q" || a == "--quiet") opt.quiet = true;
             else if (a == "-z" || a == "--include-zero") opt.include_zero = true;
             else if (a == "--include-permutations") { /* BASELINE.json's name for the reference default; no-op */ }
-            else if (a == "--pack") { const std::string v = need(i, "--pack"); opt.device_pack = v != "host"; }
+            else if (a == "--pack") {
+                const std::string v = need(i, "--pack");
+                if (v != "host" && v != "device" && v != "fastq") throw Error("invalid value '" + v + "' for '--pack'");
+                opt.device_pack = v != "host";
+                opt.device_parse = v == "fastq";
+            }
             else if (a == "-h" || a == "--help") { fputs(USAGE, stdout); return 0; }
             else if (a == "-V" || a == "--version") { puts("sgcount-hip 0.1.0 (count path of sgcount 0.1.35)"); return 0; }
             else { fprintf(stderr, "error: unexpected argument '%s' found\n\n%s", a.c_str(), USAGE); return 2; }

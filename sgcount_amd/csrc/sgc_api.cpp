@@ -268,6 +268,14 @@ int sgc_set_stream(sgc_ctx *c, void *hip_stream) {
 
 void *sgc_get_stream(sgc_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
+void *sgc_alloc_pinned(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void sgc_free_pinned(void *p) { if (p) hipHostFree(p); }
+
 int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
     if (!c || !key) return fail(SGC_E_ARG, "sgc_set_option: NULL argument");
     if (!strcmp(key, "variant")) { c->variant = (int)value; return SGC_OK; }
@@ -494,8 +502,48 @@ int sgc_sample_push_reads(sgc_sample *s, const uint8_t *seqs, const uint64_t *of
 }
 
 int sgc_sample_push_fastq(sgc_sample *s, const uint8_t *text, uint64_t n_bytes, int where, uint64_t *n_records_out) {
-    (void)s; (void)text; (void)n_bytes; (void)where; (void)n_records_out;
-    return fail(SGC_E_UNSUPPORTED, "sgc_sample_push_fastq: not built yet");
+    if (!s || (!text && n_bytes)) return fail(SGC_E_ARG, "sgc_sample_push_fastq: NULL argument");
+    if (n_records_out) *n_records_out = 0;
+    if (n_bytes == 0) return SGC_OK;
+    if (n_bytes > 0xFFF00000ull) return fail(SGC_E_ARG, "sgc_sample_push_fastq: chunk larger than 4 GiB");
+    sgc_ctx *c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint8_t *d_text = text;
+    if (where == SGC_MEM_HOST) {
+        int rc = ensure(&c->d_stage, &c->stage_cap, n_bytes);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(c->d_stage, text, n_bytes, hipMemcpyHostToDevice, c->stream));
+        d_text = (const uint8_t *)c->d_stage;
+    } else if (where != SGC_MEM_DEVICE) {
+        return fail(SGC_E_ARG, "sgc_sample_push_fastq: where must be SGC_MEM_HOST or SGC_MEM_DEVICE");
+    }
+    const uint32_t tiles = sgc_fastq_tiles(n_bytes);
+    int rc = ensure(&c->d_aux, &c->aux_cap, ((size_t)tiles + 1) * 4);
+    if (rc) return rc;
+    // a FASTQ record is at least 8 bytes ("@\n\n+\n\n" plus one base and quality): bound the record buffer
+    const uint64_t max_recs = n_bytes / 7 + 1;
+    void *p = c->d_recs; size_t cap = c->recs_cap;
+    rc = ensure(&p, &cap, (size_t)max_recs * (c->rec16 ? 16 : 8));
+    c->d_recs = (uint64_t *)p; c->recs_cap = cap;
+    if (rc) return rc;
+    {
+        timed t(c, T_PACK);
+        sgc_launch_fastq(c->stream, d_text, n_bytes, (uint32_t *)c->d_aux, c->L, c->rec16, s->reverse, s->offset,
+                         s->recursion, c->d_recs);
+    }
+    HIP_TRY(hipGetLastError());
+    uint32_t n_newlines = 0;
+    HIP_TRY(hipMemcpyAsync(&n_newlines, (uint32_t *)c->d_aux + tiles, 4, hipMemcpyDeviceToHost, c->stream));
+    uint8_t last = 0;
+    HIP_TRY(hipMemcpyAsync(&last, d_text + n_bytes - 1, 1, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint64_t lines = (uint64_t)n_newlines + (last == '\n' ? 0 : 1);
+    if (lines % 4 != 0)
+        return fail(SGC_E_ARG, "sgc_sample_push_fastq: the chunk does not hold whole 4-line records (" +
+                                   std::to_string(lines) + " lines)");
+    const uint64_t n_records = lines / 4;
+    if (n_records_out) *n_records_out = n_records;
+    return count_records(s, c->d_recs, n_records);
 }
 
 int sgc_sample_sync(sgc_sample *s) {

@@ -54,3 +54,9 @@ void sgc_launch_part_generic(hipStream_t st, uint32_t L, const sgc_table_view &l
                              unsigned long long *matched);
 void sgc_launch_part_k4(hipStream_t st, uint32_t n_guides, const sgc_part_geometry &g, const uint32_t *gids,
                         const uint32_t *seg_cnt, uint32_t *counts, unsigned long long *matched);
+
+// ---- FASTQ ingest (sgc_fastq.hip) -----------------------------------------------------------------
+// tile_scratch: sgc_fastq_tiles(n) + 1 u32; after the call tile_scratch[tiles] = number of '\n' in the text
+uint32_t sgc_fastq_tiles(uint64_t n);
+void sgc_launch_fastq(hipStream_t st, const uint8_t *text, uint64_t n, uint32_t *tile_scratch, uint32_t L, bool rec16,
+                      int reverse, uint32_t o, int recursion, uint64_t *recs);

@@ -53,7 +53,7 @@ def test_single_sample_fixed_offset_exact(cli, example_library_text, example_rea
     assert err == ""
 
 
-@pytest.mark.parametrize("pack", ["device", "host"])
+@pytest.mark.parametrize("pack", ["fastq", "device", "host"])
 def test_all_samples_auto_offset_genemap_zero(cli, pack, tmp_path, example_library_text, example_reads):
     paths = [os.path.join(DATA, n + ".fastq.gz") for n in NAMES]
     g2s = os.path.join(DATA, "g2s.txt")

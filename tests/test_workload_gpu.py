@@ -80,3 +80,72 @@ def test_synthetic_workload_vs_oracle_2m(env, exact):
     c2, t2, m2 = wl.result()
     assert (c2.tolist(), t2, m2) == (counts.tolist(), total, matched)
     wl.close()
+
+
+@pytest.mark.parametrize("L,reverse,recursion", [(20, False, True), (20, True, False), (27, False, True)])
+def test_fastq_ingest_on_device(env, L, reverse, recursion):
+    """sgc_sample_push_fastq: record boundaries + packing on the GPU from raw FASTQ text == the oracle fed the
+    same text; chunked pushes (record-aligned), device- and host-resident text, missing final newline."""
+    import ctypes as C
+    torch, S, synth, workload = env
+    ffi = S._ffi
+    n, ng = 60_000, 3000
+    lib_seqs, library = workload.synth_library(ng, L)
+    text = synth.fastq_host(lib_seqs, 777, n, mode=1)
+    # sprinkle non-ACGT bytes into sequence lines only (line 1 of every record)
+    lines = text.split(b"\n")
+    rng = np.random.default_rng(9)
+    for i in rng.integers(0, n, 3000):
+        s = bytearray(lines[4 * i + 1])
+        if s:
+            s[rng.integers(0, len(s))] = rng.choice(np.frombuffer(b"NNNnRJ", dtype=np.uint8))
+            lines[4 * i + 1] = bytes(s)
+    lines[4 * 5 + 1] = b""                       # an empty read
+    lines[4 * 5 + 3] = b""
+    text = b"\n".join(lines)
+    lib_text = synth.library_fasta(lib_seqs)
+    want, tot, mat = O.count_text(lib_text, text, reverse, 30, False, recursion)
+    dl = library.device(True)
+    dl.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def run(chunks, where):
+        smp = C.c_void_p()
+        ffi.check(dl.lib.sgc_sample_begin(dl.ctx, C.byref(smp), int(reverse), 30, int(recursion)))
+        total = 0
+        keep = []
+        for ch in chunks:
+            nrec = C.c_uint64(0)
+            if where == ffi.MEM_DEVICE:
+                d = torch.frombuffer(bytearray(ch), dtype=torch.uint8).cuda()
+                keep.append(d)
+                ffi.check(dl.lib.sgc_sample_push_fastq(smp, d.data_ptr(), len(ch), where, C.byref(nrec)))
+            else:
+                ffi.check(dl.lib.sgc_sample_push_fastq(smp, ch, len(ch), where, C.byref(nrec)))
+            total += nrec.value
+        out = np.zeros(ng, dtype=np.uint64)
+        t, m = C.c_uint64(), C.c_uint64()
+        ffi.check(dl.lib.sgc_sample_finish(smp, out.ctypes.data, C.byref(t), C.byref(m)))
+        dl.lib.sgc_sample_free(smp)
+        assert total == t.value
+        return out.tolist(), t.value, m.value
+
+    assert run([text], ffi.MEM_HOST) == (want, tot, mat)
+    assert run([text[:-1]], ffi.MEM_DEVICE) == (want, tot, mat)          # no trailing newline
+    # record-aligned chunks of uneven size (a chunk boundary may fall anywhere relative to the 4 KiB tiles)
+    cuts = [0]
+    pos = 0
+    for k in (1, 7, 100, 4097, 20000):
+        for _ in range(4 * k):
+            pos = text.index(b"\n", pos) + 1
+        cuts.append(pos)
+    cuts.append(len(text))
+    chunks = [text[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    assert run(chunks, ffi.MEM_DEVICE) == (want, tot, mat)
+    # a chunk that is not a whole number of records is rejected
+    smp = C.c_void_p()
+    ffi.check(dl.lib.sgc_sample_begin(dl.ctx, C.byref(smp), 0, 30, 1))
+    bad = text[: text.index(b"\n", 5000) + 1]
+    if bad.count(b"\n") % 4 == 0:
+        bad = bad[: bad.rindex(b"\n", 0, len(bad) - 1) + 1]
+    assert dl.lib.sgc_sample_push_fastq(smp, bad, len(bad), ffi.MEM_HOST, None) == ffi.E_ARG
+    dl.lib.sgc_sample_free(smp)
