@@ -35,6 +35,8 @@ enum { T_LOOKUP = 0, T_HIST = 1, T_PACK = 2, T_PART = 3, T_MISS = 4, T_KINDS = 5
 struct sgc_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t side_stream = nullptr;          // k_generic runs beside k_resolve_miss (fork/join with events)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // library
     bool has_lib = false, one_mm = false, rec16 = false;
     uint32_t n = 0, L = 0;
@@ -152,10 +154,15 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
             if (rc) return rc;
             rc = ensure(&c->d_aux, &c->aux_cap, ((size_t)g.n_segs + 1) * 4);
             if (rc) return rc;
-            { timed t(c, T_MISS); sgc_launch_part_generic(c->stream, c->L, c->v_lib, c->v_perm, c->one_mm, g, pool, desc,
-                                                          s->d_c32, s->d_matched); }
+            // k_generic (serial chains, no LDS) runs beside k_resolve_miss (LDS-heavy, one workgroup per CU):
+            // fork to the side stream here, join before the histogram
+            HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+            HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+            sgc_launch_part_generic(c->side_stream, c->L, c->v_lib, c->v_perm, c->one_mm, g, pool, desc, s->d_c32, s->d_matched);
+            HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
             { timed t(c, T_MISS); sgc_launch_part_k3(c->stream, c->L, c->v_lib, c->v_perm, c->one_mm, c->b_lib, c->b_perm, g, pool, desc,
                                                      (uint32_t *)c->d_aux, (uint32_t *)c->d_gids, c->dbg); }
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
             { timed t(c, T_HIST); sgc_launch_part_k4(c->stream, c->n, g, (const uint32_t *)c->d_gids,
                                                      (const uint32_t *)c->d_aux, s->d_c32, s->d_matched); }
         } else if (c->variant == 0) {
@@ -222,6 +229,12 @@ int sgc_init(int device, sgc_ctx **out) {
     e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(SGC_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
     c->stream = c->own_stream;
+    if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        sgc_free(c);
+        return fail(SGC_E_HIP, "sgc_init: cannot create the side stream");
+    }
     if (const char *v = getenv("SGC_VARIANT")) c->variant = atoi(v);
     *out = c;
     return SGC_OK;
@@ -254,6 +267,9 @@ void sgc_free(sgc_ctx *c) {
     if (c->d_gids) hipFree(c->d_gids);
     if (c->d_pool) hipFree(c->d_pool);
     if (c->d_desc) hipFree(c->d_desc);
+    if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
