@@ -424,8 +424,8 @@ int sgc_pack_reads_device(sgc_ctx *c, const uint8_t *d_seqs, const uint64_t *d_o
     HIP_TRY(hipSetDevice(c->device));
     {
         timed t(c, T_PACK);
-        sgc_launch_pack_reads(c->stream, d_seqs, d_offsets, n, c->L, c->rec16, reverse != 0, offset,
-                              position_recursion != 0, (uint64_t *)d_records_out);
+        sgc_launch_pack_reads_lds(c->stream, d_seqs, d_offsets, n, c->L, c->rec16, reverse != 0, offset,
+                                  position_recursion != 0, (uint64_t *)d_records_out);
     }
     HIP_TRY(hipGetLastError());
     return SGC_OK;
@@ -510,8 +510,8 @@ int sgc_sample_push_reads(sgc_sample *s, const uint8_t *seqs, const uint64_t *of
     if (rc) return rc;
     {
         timed t(c, T_PACK);
-        sgc_launch_pack_reads(c->stream, d_seqs, d_off, n, c->L, c->rec16, s->reverse, s->offset, s->recursion,
-                              c->d_recs);
+        sgc_launch_pack_reads_lds(c->stream, d_seqs, d_off, n, c->L, c->rec16, s->reverse, s->offset, s->recursion,
+                                  c->d_recs);
     }
     HIP_TRY(hipGetLastError());
     return count_records(s, c->d_recs, n);

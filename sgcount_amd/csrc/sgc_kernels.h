@@ -60,3 +60,5 @@ void sgc_launch_part_k4(hipStream_t st, uint32_t n_guides, const sgc_part_geomet
 uint32_t sgc_fastq_tiles(uint64_t n);
 void sgc_launch_fastq(hipStream_t st, const uint8_t *text, uint64_t n, uint32_t *tile_scratch, uint32_t L, bool rec16,
                       int reverse, uint32_t o, int recursion, uint64_t *recs);
+void sgc_launch_pack_reads_lds(hipStream_t st, const uint8_t *seqs, const uint64_t *offsets, uint64_t n, uint32_t L,
+                               bool rec16, int reverse, uint32_t o, int recursion, uint64_t *recs);
