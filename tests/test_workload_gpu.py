@@ -149,3 +149,76 @@ def test_fastq_ingest_on_device(env, L, reverse, recursion):
         bad = bad[: bad.rindex(b"\n", 0, len(bad) - 1) + 1]
     assert dl.lib.sgc_sample_push_fastq(smp, bad, len(bad), ffi.MEM_HOST, None) == ffi.E_ARG
     dl.lib.sgc_sample_free(smp)
+
+
+def test_auto_offset_stagger_workload(env, tmp_path):
+    """BASELINE.json configs[3]: variable-stagger reads (prefix 28..32), no -a: the offsetter must find
+    Forward(30) on the first 5000 reads, and the counts with that offset must equal the oracle's."""
+    import os
+    torch, S, synth, workload = env
+    from sgcount_amd import hostlib
+    n, ng = 300_000, 5000
+    wl = workload.DeviceWorkload(n, ng, 20, one_mismatch=True, mode=synth.MODE_STAGGER, gen_chunk=100_000)
+    lib_text = synth.library_fasta(wl.lib_seqs)
+    fq = synth.fastq_host(wl.lib_seqs, 0, n, mode=synth.MODE_STAGGER)
+    lp, rp = os.path.join(str(tmp_path), "lib.fa"), os.path.join(str(tmp_path), "reads.fq")
+    open(lp, "wb").write(lib_text)
+    open(rp, "wb").write(fq)
+    assert hostlib.entropy_offset_group(lp, [rp]) == [(False, 30)] == [O.entropy_offset(lib_text, fq)]
+    wl.step()
+    counts, total, matched = wl.result()
+    want, tot, mat = O.count_text(lib_text, fq, False, 30, False, True)
+    assert (counts.tolist(), total, matched) == (want, tot, mat)
+    # prefix 29/31 are rescued by the position recursion, 28/32 are not: roughly 10 % of the guide reads are lost
+    assert 0.80 < matched / total < 0.90
+    wl.close()
+
+
+def test_full_size_properties(env):
+    """BASELINE.json's full size (100k guides, 100M reads) through size-independent properties: totals, the
+    count-sum invariant, linearity of the fold over a split, agreement of every kernel variant, and the
+    oracle on a prefix."""
+    torch, S, synth, workload = env
+    ffi = S._ffi
+    n, ng = 100_000_000, 100_000
+    wl = workload.DeviceWorkload(n, ng, 20, one_mismatch=True)
+    wl.step()
+    counts, total, matched = wl.result()
+    assert total == n and int(counts.sum()) == matched
+    assert 0.945 < matched / total < 0.955                     # 85+5+1+2+2 % of the classes can match
+    # hot guides (every 100th) carry 50x weight
+    hot = counts[::100].astype(np.float64).mean()
+    cold = np.delete(counts, np.arange(0, ng, 100)).astype(np.float64).mean()
+    assert 45 < hot / cold < 55
+    # linearity: two pushes accumulate to the same table
+    ffi.check(wl.abi.sgc_sample_reset(wl.sample))
+    cut = 37_000_001
+    for first, m in ((0, cut), (cut, n - cut)):
+        ffi.check(wl.abi.sgc_sample_push_packed(wl.sample, wl.records.data_ptr() + 8 * first, m, ffi.MEM_DEVICE))
+    ffi.check(wl.abi.sgc_sample_export_device(wl.sample, wl.export.data_ptr()))
+    c2, t2, m2 = wl.result()
+    assert t2 == total and m2 == matched and np.array_equal(c2, counts)
+    # every variant of the count path gives the same table
+    for v in (0, 1, 2):
+        wl.dl.set_option("variant", v)
+        wl.step()
+        cv, tv, mv = wl.result()
+        assert tv == total and mv == matched and np.array_equal(cv, counts), v
+    wl.dl.set_option("variant", 3)
+    # small internal chunks (several pool generations per push)
+    wl.dl.set_option("max_chunk", 9_000_000)
+    wl.step()
+    cc, tc, mc = wl.result()
+    assert mc == matched and np.array_equal(cc, counts)
+    wl.dl.set_option("max_chunk", 1 << 27)
+    # oracle on the first 1.5M reads
+    m = 1_500_000
+    wl.step(0, m)
+    cp, tp, mp = wl.result()
+    lib_text = synth.library_fasta(wl.lib_seqs)
+    lib = O.Library(lib_text)
+    ctr = O.Counter(lib, O.Permuter(lib), False, 30, 20, True)
+    for first in range(0, m, 500_000):
+        ctr.feed_text(synth.fastq_host(wl.lib_seqs, first, 500_000))
+    assert (cp.tolist(), tp, mp) == (ctr.table(), ctr.total_reads(), ctr.matched_reads())
+    wl.close()
