@@ -130,29 +130,53 @@ void sgc_build_permute_table(const std::vector<uint64_t> &keys, uint32_t L, cons
                              sgc_host_table &out, std::vector<uint64_t> *child_keys) {
     const uint32_t n = (uint32_t)keys.size();
     const uint32_t gb = lib.gid_bits;
-    // all (child, parent) pairs: 3 ACGT substitutions per position (src/permutes.rs:78-107 minus the 'N' column)
-    std::vector<std::pair<uint64_t, uint32_t>> kids;
-    kids.reserve((size_t)n * 3 * L);
-    for (uint32_t g = 0; g < n; g++) {
-        const uint64_t k = keys[g];
-        for (uint32_t j = 0; j < L; j++)
-            for (uint64_t d = 1; d < 4; d++) kids.emplace_back(k ^ (d << (2 * j)), g);
+    // all (child, parent) pairs: 3 ACGT substitutions per position (src/permutes.rs:78-107 minus the 'N' column).
+    // The table is sized for all of them (nearly all survive); children are ordered by their home bucket with a
+    // two-pass radix sort, so that duplicate children meet in one bucket run and the inserts walk the table
+    // sequentially instead of missing the cache 6 M times.
+    struct Kid { uint64_t key; uint32_t bucket, gid; };
+    const size_t total = (size_t)n * 3 * L;
+    table_alloc(out, total, 0.5, gb);
+    const uint32_t log2_buckets = out.log2_slots - 1;
+    std::vector<Kid> a(total), b(total);
+    {
+        size_t w = 0;
+        for (uint32_t g = 0; g < n; g++) {
+            const uint64_t k = keys[g];
+            for (uint32_t j = 0; j < L; j++)
+                for (uint64_t d = 1; d < 4; d++) {
+                    const uint64_t c = k ^ (d << (2 * j));
+                    a[w++] = Kid{c, sgc_home_bucket(c, out.log2_slots), g};
+                }
+        }
     }
-    std::sort(kids.begin(), kids.end());
-    // keep children with exactly one parent that are not library members (src/permutes.rs:127-144: a
-    // second sighting moves the child to `null`; a parent is in `null` from the start)
-    std::vector<std::pair<uint64_t, uint32_t>> keep;
-    keep.reserve(kids.size());
-    for (size_t i = 0; i < kids.size();) {
+    const uint32_t lo_bits = log2_buckets / 2, hi_bits = log2_buckets - lo_bits;
+    auto radix_pass = [&](std::vector<Kid> &src, std::vector<Kid> &dst, uint32_t shift, uint32_t bits) {
+        std::vector<size_t> cnt((size_t)1 << bits, 0);
+        const uint32_t mask = (1u << bits) - 1u;
+        for (const Kid &x : src) cnt[(x.bucket >> shift) & mask]++;
+        size_t run = 0;
+        for (auto &c : cnt) { const size_t v = c; c = run; run += v; }
+        for (const Kid &x : src) dst[cnt[(x.bucket >> shift) & mask]++] = x;
+    };
+    radix_pass(a, b, 0, lo_bits);
+    radix_pass(b, a, lo_bits, hi_bits);
+    // per bucket run: keep children with exactly one parent that are not library members (src/permutes.rs:127-144:
+    // a second sighting moves the child to `null`; a parent is in `null` from the start)
+    if (child_keys) { child_keys->clear(); child_keys->reserve(total); }
+    for (size_t i = 0; i < total;) {
         size_t j = i + 1;
-        while (j < kids.size() && kids[j].first == kids[i].first) j++;
-        if (j - i == 1 && table_find_host(lib, kids[i].first) == SGC_NONE) keep.push_back(kids[i]);
+        while (j < total && a[j].bucket == a[i].bucket) j++;
+        if (j - i > 1) std::sort(a.begin() + i, a.begin() + j, [](const Kid &x, const Kid &y) { return x.key < y.key; });
+        for (size_t u = i; u < j;) {
+            size_t v = u + 1;
+            while (v < j && a[v].key == a[u].key) v++;
+            if (v - u == 1 && table_find_host(lib, a[u].key) == SGC_NONE) {
+                table_insert(out, a[u].key, a[u].gid);
+                if (child_keys) child_keys->push_back(a[u].key);
+            }
+            u = v;
+        }
         i = j;
-    }
-    table_alloc(out, keep.size(), 0.5, gb);
-    for (const auto &kv : keep) table_insert(out, kv.first, kv.second);
-    if (child_keys) {
-        child_keys->resize(keep.size());
-        for (size_t i = 0; i < keep.size(); i++) (*child_keys)[i] = keep[i].first;
     }
 }
