@@ -355,9 +355,12 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
         rc = upload_table(h_perm, &c->d_perm_slots, &c->d_perm_vals, &c->v_perm, c->stream);
         if (rc != SGC_OK) { free_tables(c); return rc; }
         c->perm_entries = h_perm.entries;
-        // ~5.6 bits per child: 6.0 M children -> 2^19 words = 4 MiB (the XCD L2 size)
-        rc = upload_bloom(child_keys, sgc_bloom_log2_words(child_keys.size(), 4, 10, 24), &c->d_bloom_perm, &c->b_perm,
-                          c->stream);
+        {
+            uint32_t bpk = 8;                    // bits per child, rounded up to a power-of-two word count: 6.0 M children -> 8 MiB
+            if (const char *v = getenv("SGC_PERM_BLOOM_BITS")) bpk = (uint32_t)std::max(1, atoi(v));
+            rc = upload_bloom(child_keys, sgc_bloom_log2_words(child_keys.size(), bpk, 10, 24), &c->d_bloom_perm, &c->b_perm,
+                              c->stream);
+        }
         if (rc != SGC_OK) { free_tables(c); return rc; }
     }
     c->n = n; c->L = L; c->one_mm = enable_1mm != 0; c->rec16 = L > SGC_REC8_MAXL; c->has_lib = true;

@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(K2_THREADS) k_count_slices(uint64_t *__restric
 //   round B'  permute(P), permute(M) buckets if their filters passed
 // and the results are taken in the reference's order C-1mm, P-exact, P-1mm, M-exact, M-1mm
 // (src/counter.rs:113-135).  Guide ids go to gids[segment * K3_SEG * BLOCK + i]; seg_cnt[segment] = count.
-#define K3_SEG 16u
+#define K3_SEG 64u
 #define K3_THREADS 1024u
 #define K3_STAGE 8192u
 #define K3_R 2u
@@ -331,8 +331,8 @@ __global__ void __launch_bounds__(K3_THREADS) k_resolve_miss(const uint64_t *__r
         // for one or two lanes.
         if (t == 0) { n_fast = 0; n_slow = 0; }
         __syncthreads();
-        {
-            const uint32_t u = t >> 6, lane = t & 63u;
+        for (uint32_t u = t >> 6; u < K3_SEG; u += K3_THREADS / 64) {
+            const uint32_t lane = t & 63u;
             const uint64_t *blkp = pool + (uint64_t)(b0 + u) * PART_BLOCK;
             for (uint32_t j = lane; j < m_[u]; j += 64) {
                 const uint32_t d = off_[u] + j;
