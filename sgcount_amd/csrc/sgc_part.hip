@@ -28,13 +28,13 @@
 #include "sgc_format.h"
 #include "sgc_kernels.h"
 
-#define PART_TILE 2048u          // records staged per tile in K1 (== block size)
-#define PART_BLOCK 2048u         // records per block
+#define PART_TILE 2048u          // records staged per tile in K1
+#define PART_BLOCK 1024u         // records per block (small blocks: fewer empty slots in the open blocks K1 leaves)
 #define PART_MAXP 64u            // max library slices; partition index PART_MAXP' = P_lib is the generic one
 #define PART_ARR (PART_MAXP + 1u)
 #define DESC_FILL_MASK 0xFFFFu
 
-static_assert(PART_TILE <= PART_BLOCK, "a tile must fit one block");
+static_assert(PART_TILE % PART_BLOCK == 0 || PART_BLOCK % PART_TILE == 0, "tile/block sizes must nest");
 
 // Partition of a record: the library slice of its Centered key, or — for records whose status is non-zero
 // (an 'N', a dead window, a short read; ~2 % of reads) — the extra "generic" partition P_lib.  Those records
@@ -113,10 +113,15 @@ __global__ void __launch_bounds__(256) k_partition(const uint64_t *__restrict__ 
                     dst_a[q] = head ? blk[q] * PART_BLOCK + fill[q] : 0;
                     fill[q] += head;
                     if (c > head) {
+                        // the remainder goes to nb CONSECUTIVE new blocks (contiguous in the pool): all but the
+                        // last are full
+                        const uint32_t rem = c - head, nb = (rem + PART_BLOCK - 1) / PART_BLOCK;
                         if (blk[q] != 0xFFFFFFFFu) desc[blk[q]] = ((q + 1) << 16) | PART_BLOCK;    // close, full
-                        blk[q] = block0 + atomicAdd(&next_free, 1u);
-                        dst_b[q] = blk[q] * PART_BLOCK;
-                        fill[q] = c - head;
+                        const uint32_t x = block0 + atomicAdd(&next_free, nb);
+                        for (uint32_t i = 0; i + 1 < nb; i++) desc[x + i] = ((q + 1) << 16) | PART_BLOCK;
+                        blk[q] = x + nb - 1;
+                        dst_b[q] = x * PART_BLOCK;
+                        fill[q] = rem - (nb - 1) * PART_BLOCK;
                     }
                 }
             }
@@ -143,9 +148,13 @@ __global__ void __launch_bounds__(256) k_partition(const uint64_t *__restrict__ 
 // ------------------------------------------------------------------------------------------------ K2
 #define K2_THREADS 1024u
 #define K2_LIST 2048u            // capacity of the per-round block list
-#define K2_U 4u                  // blocks per group: one group is processed while the next is in flight
+#ifndef K2_U
+#define K2_U 8u 
+#endif
+//                 // blocks per group: one group is processed while the next is in flight
+#define K2_SCAN 16u              // descriptors examined per lane per scan chunk
 template <int LOG2_SLICE>
-__global__ void __launch_bounds__(K2_THREADS) k_count_slices(uint64_t *__restrict__ pool, uint32_t *__restrict__ desc,
+__global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(80))) k_count_slices(uint64_t *__restrict__ pool, uint32_t *__restrict__ desc,
                                                              uint32_t n_blocks, uint32_t G, uint32_t L,
                                                              sgc_table_view lib, uint32_t *__restrict__ counts,
                                                              unsigned long long *__restrict__ matched, uint32_t dbg) {
@@ -155,11 +164,10 @@ __global__ void __launch_bounds__(K2_THREADS) k_count_slices(uint64_t *__restric
     __shared__ ulonglong2 tab[S / 2];                        // the slice, bucket by bucket
     __shared__ uint32_t cnt[S];
     __shared__ uint32_t list[K2_LIST];                       // block id << 11 | (fill - 1)
-    __shared__ uint32_t n_list, miss_cnt[2][K2_U];
+    __shared__ uint32_t n_list, over_at, miss_cnt[2][K2_U];
     const uint32_t t = threadIdx.x, p = blockIdx.x / G, g = blockIdx.x % G;
     const uint32_t slice = lib.log2_slice < (uint32_t)LOG2_SLICE ? (1u << lib.log2_slice) : S;   // small libraries
     const uint32_t bmask = slice / 2 - 1u, gid_bits = lib.gid_bits;
-    const uint32_t sh = 2 * (L + 2);
     const uint64_t kmask = sgc_key_mask(L);
     const ulonglong2 *gtab = reinterpret_cast<const ulonglong2 *>(lib.slots) + (uint64_t)p * (slice / 2);
     for (uint32_t i = t; i < S / 2; i += K2_THREADS) {      // bare keys in LDS (a key is < 2^60, so SGC_EMPTY stays distinct)
@@ -170,52 +178,81 @@ __global__ void __launch_bounds__(K2_THREADS) k_count_slices(uint64_t *__restric
     }
     for (uint32_t i = t; i < S; i += K2_THREADS) cnt[i] = 0;
     if (t < 2 * K2_U) miss_cnt[t / K2_U][t % K2_U] = 0;
-    // descriptors are scanned in windows; the blocks of partition p whose id hashes to g are listed, then
-    // processed (a plain id % G would hand one workgroup ALL blocks of a partition: K1 opens blocks for the
-    // partitions in a repeating order)
-    const uint32_t window = (K2_LIST / 2) * G;      // <= K2_LIST/2 expected matches per round even if every block is p's
-    for (uint32_t win = 0; win < n_blocks; win += window) {
-        if (t == 0) n_list = 0;
+    // diagnostic stamps (dbg & 512): cycle counts of the phases of a few workgroups, printed at the end
+    unsigned long long ts0 = 0, ts_scan = 0, ts_loop = 0;
+    uint32_t n_groups_dbg = 0;
+    if (dbg & 512) ts0 = __builtin_amdgcn_s_memtime();
+    // The descriptors are scanned in chunks; the blocks of partition p whose id hashes to g are listed (a plain
+    // id % G would hand one workgroup ALL blocks of a partition: K1 opens blocks for the partitions in a
+    // repeating order).  Scanning goes on until the list is half full or the descriptors are exhausted, so that
+    // the software pipeline below runs over one long list (typically all of the workgroup's blocks).  If a
+    // chunk overflows the list (extreme skew), the ids from the first rejected one on are dropped and rescanned.
+    uint32_t win = 0;
+    while (win < n_blocks) {
+        if (t == 0) { n_list = 0; over_at = 0xFFFFFFFFu; }
         __syncthreads();
-        for (uint32_t k = t; k < window; k += K2_THREADS) {
-            const uint32_t b = win + k;
-            if (b < n_blocks && ((b * 0x9E3779B1u) >> 16) % G == g) {
-                const uint32_t d = desc[b];
-                if ((d >> 16) == p + 1 && (d & DESC_FILL_MASK)) {
+        uint32_t w = win;
+        for (;;) {
+            uint32_t dd[K2_SCAN];                  // all loads of the chunk first (coalesced, in flight together)
+#pragma unroll
+            for (uint32_t k = 0; k < K2_SCAN; k++) {
+                const uint32_t b = w + k * K2_THREADS + t;
+                dd[k] = b < n_blocks ? desc[b] : 0;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < K2_SCAN; k++) {
+                const uint32_t b = w + k * K2_THREADS + t;
+                if ((dd[k] >> 16) == p + 1 && (dd[k] & DESC_FILL_MASK) && (((b * 0x9E3779B1u) >> 16) & (G - 1u)) == g) {   // G = 2^k
                     const uint32_t at = atomicAdd(&n_list, 1u);
-                    if (at < K2_LIST) list[at] = (b << 11) | ((d & DESC_FILL_MASK) - 1u);   // cannot overflow: tests/test_abi_cpu.py::test_k2_window_bound
+                    if (at < K2_LIST) list[at] = (b << 11) | ((dd[k] & DESC_FILL_MASK) - 1u);
+                    else atomicMin(&over_at, b);
                 }
             }
+            w += K2_SCAN * K2_THREADS;
+            __syncthreads();
+            const bool stop = w >= n_blocks || n_list >= K2_LIST / 2;
+            __syncthreads();
+            if (stop) break;
         }
+        const uint32_t nl = n_list < K2_LIST ? n_list : K2_LIST, oa = over_at;
+        if (dbg & 512) { ts_scan += __builtin_amdgcn_s_memtime() - ts0; ts0 = __builtin_amdgcn_s_memtime(); n_groups_dbg += (nl + K2_U - 1) / K2_U; }
+        for (uint32_t i = t; i < nl; i += K2_THREADS)
+            if ((list[i] >> 11) >= oa) list[i] = 0xFFFFFFFFu;            // dropped: rescanned in the next round
         __syncthreads();
-        const uint32_t nl = n_list < K2_LIST ? n_list : K2_LIST;
-        // software pipeline over groups of K2_U blocks: `cur` is processed while `nxt` is in flight
+        win = w < oa ? w : oa;
+        // software pipeline over groups of K2_U blocks: `cur` is processed while `nxt` is in flight.  Block ids and
+        // fills are wave-uniform (scalar registers).
         uint64_t cur[Q], nxt[Q];
-        uint32_t cur_valid = 0, nxt_valid = 0;
+        uint32_t ce[K2_U];                // list entries (block id << 11 | fill - 1; all ones = none), wave-uniform
 #pragma unroll
-        for (uint32_t q = 0; q < Q; q++) {
-            const uint32_t u = q / RPT, j = (q % RPT) * K2_THREADS + t;
-            const uint32_t e = u < nl ? list[u] : 0;
-            const bool ok = u < nl && j <= (e & 2047u);
-            cur[q] = ok ? pool[(uint64_t)(e >> 11) * PART_BLOCK + j] : 0;
-            if (ok) cur_valid |= 1u << q;
+        for (uint32_t u = 0; u < K2_U; u++) {
+            ce[u] = __builtin_amdgcn_readfirstlane(u < nl ? list[u] : 0xFFFFFFFFu);
+#pragma unroll
+            for (uint32_t k = 0; k < RPT; k++) {
+                const uint32_t j = k * K2_THREADS + t;
+                // a block has room for PART_BLOCK records: lanes past its fill read (and later ignore) stale slots
+                cur[u * RPT + k] = pool[(uint64_t)(ce[u] == 0xFFFFFFFFu ? 0u : ce[u] >> 11) * PART_BLOCK + j];
+            }
         }
         for (uint32_t li = 0; li < nl; li += K2_U) {
             const uint32_t par = (li / K2_U) & 1u;
             // all records of group li are in registers (this also publishes the previous group's miss counts)
             __syncthreads();
             if (t < K2_U) {
-                if (li) desc[list[li - K2_U + t] >> 11] = ((p + 1) << 16) | miss_cnt[par ^ 1u][t];
+                if (li) {
+                    const uint32_t e = list[li - K2_U + t];
+                    if (e != 0xFFFFFFFFu) desc[e >> 11] = ((p + 1) << 16) | miss_cnt[par ^ 1u][t];
+                }
                 miss_cnt[par ^ 1u][t] = 0;
             }
-            nxt_valid = 0;
 #pragma unroll
-            for (uint32_t q = 0; q < Q; q++) {
-                const uint32_t u = li + K2_U + q / RPT, j = (q % RPT) * K2_THREADS + t;
-                const uint32_t e = u < nl ? list[u] : 0;
-                const bool ok = u < nl && j <= (e & 2047u);
-                nxt[q] = ok ? pool[(uint64_t)(e >> 11) * PART_BLOCK + j] : 0;
-                if (ok) nxt_valid |= 1u << q;
+            for (uint32_t u = 0; u < K2_U; u++) {
+                const uint32_t ne = __builtin_amdgcn_readfirstlane(li + K2_U + u < nl ? list[li + K2_U + u] : 0xFFFFFFFFu);
+#pragma unroll
+                for (uint32_t k = 0; k < RPT; k++) {
+                    const uint32_t j = k * K2_THREADS + t;
+                    nxt[u * RPT + k] = pool[(uint64_t)(ne == 0xFFFFFFFFu ? 0u : ne >> 11) * PART_BLOCK + j];
+                }
             }
             // Centered-exact probe (src/counter.rs:111) of the Q records against the slice in LDS.  The LDS copy
             // holds bare keys, so a bucket resolves with four 64-bit compares and no branches (K2 is bound by
@@ -223,38 +260,48 @@ __global__ void __launch_bounds__(K2_THREADS) k_count_slices(uint64_t *__restric
             // a loop.  An insert fills slot 0 before slot 1, so "slot 1 free" means "chain ends here".
 #pragma unroll
             for (uint32_t q = 0; q < Q; q++) {
+                // K1 sends every record with a non-zero status to the generic partition, so a slice partition
+                // only holds clean records: no status test here
+                const uint32_t u = q / RPT, j = (q % RPT) * K2_THREADS + t;
+                const bool valid = ce[u] != 0xFFFFFFFFu && j <= (ce[u] & 2047u);
                 const uint64_t key = (cur[q] >> 2) & kmask;
                 uint32_t b = sgc_home_bucket(key, lib.log2_slots) & bmask;
-                ulonglong2 w = tab[b];
-                const bool want = (cur_valid >> q & 1u) && (cur[q] >> sh) == 0 && !(dbg & 4);
-                bool hit = want && (w.x == key || w.y == key);
-                bool cont = want && !hit && w.y != SGC_EMPTY;
+                ulonglong2 wv = tab[b];
+                bool hit = wv.x == key || wv.y == key;
+                bool cont = valid && !hit && wv.y != SGC_EMPTY;
                 while (cont) {
                     b = (b + 1) & bmask;
-                    w = tab[b];
-                    hit = w.x == key || w.y == key;
-                    cont = !hit && w.y != SGC_EMPTY && !(dbg & 8);
+                    wv = tab[b];
+                    hit = wv.x == key || wv.y == key;
+                    cont = !hit && wv.y != SGC_EMPTY;
                 }
-                if (hit && !(dbg & 1)) atomicAdd(&cnt[2 * b + (w.x == key ? 0u : 1u)], 1u);
-                if ((cur_valid >> q & 1u) && !hit && !(dbg & 2)) {
-                    const uint32_t e = list[li + q / RPT];
-                    pool[(uint64_t)(e >> 11) * PART_BLOCK + atomicAdd(&miss_cnt[par][q / RPT], 1u)] = cur[q];
+                if (valid) {
+                    if (hit) atomicAdd(&cnt[2 * b + (wv.x == key ? 0u : 1u)], 1u);
+                    else pool[(uint64_t)(ce[u] >> 11) * PART_BLOCK + atomicAdd(&miss_cnt[par][u], 1u)] = cur[q];
                 }
             }
 #pragma unroll
             for (uint32_t q = 0; q < Q; q++) cur[q] = nxt[q];
-            cur_valid = nxt_valid;
+#pragma unroll
+            for (uint32_t u = 0; u < K2_U; u++)
+                ce[u] = __builtin_amdgcn_readfirstlane(li + K2_U + u < nl ? list[li + K2_U + u] : 0xFFFFFFFFu);
         }
         __syncthreads();
         if (nl) {
             const uint32_t last = ((nl - 1) / K2_U) * K2_U, par = (last / K2_U) & 1u;
             if (t < K2_U) {
-                if (last + t < nl) desc[list[last + t] >> 11] = ((p + 1) << 16) | miss_cnt[par][t];
+                if (last + t < nl) {
+                    const uint32_t e = list[last + t];
+                    if (e != 0xFFFFFFFFu) desc[e >> 11] = ((p + 1) << 16) | miss_cnt[par][t];
+                }
                 miss_cnt[par][t] = 0;
             }
         }
         __syncthreads();
+        if (dbg & 512) { ts_loop += __builtin_amdgcn_s_memtime() - ts0; ts0 = __builtin_amdgcn_s_memtime(); }
     }
+    if ((dbg & 512) && t == 0 && (blockIdx.x % 97) == 0)
+        printf("K2 wg %u slice %u: scan %llu loop %llu cycles, %u groups\n", blockIdx.x, p, ts_scan, ts_loop, n_groups_dbg);
     // flush the slot counters: one atomic per occupied slot
     uint64_t local = 0;
     for (uint32_t i = t; i < slice; i += K2_THREADS) {
@@ -511,7 +558,7 @@ void sgc_part_plan(uint64_t n, const sgc_table_view &lib, sgc_part_geometry *g) 
     uint64_t per = (tiles + wgs - 1) / wgs * PART_TILE;                 // records per K1 workgroup, whole tiles
     g->k1_wgs = wgs;
     g->per_wg = per;
-    g->blocks_per_wg = (uint32_t)(per / PART_BLOCK) + P + 1;           // full blocks + one open block per partition (+ generic)
+    g->blocks_per_wg = (uint32_t)(per / PART_BLOCK) + P + 1;           // full blocks + one open block per partition (incl. generic)
     g->n_blocks = wgs * g->blocks_per_wg;
     g->pool_bytes = (uint64_t)g->n_blocks * PART_BLOCK * 8;
     g->desc_bytes = (uint64_t)g->n_blocks * 4;

@@ -77,17 +77,12 @@ def test_host_packer_rejects_unsupported_length():
         S.pack_reads_host([b"A" * 40], 31, S.Offset.Forward(0), True)
 
 
-def test_k2_window_bound():
-    """sgc_part.hip K2 lists, per round, the block ids b of a window of (K2_LIST/2)*G ids with
-    ((b * 0x9E3779B1) mod 2^32 >> 16) % G == g.  That count is a property of the ids alone; it must stay
-    below K2_LIST = 2048 for every window start and every (G, g), or blocks would be skipped."""
-    K2_LIST = 2048
-    for G in (8, 16, 32, 64, 128, 256, 512):
-        window = (K2_LIST // 2) * G
-        ids = np.arange(0, 1 << 21, dtype=np.uint64)
-        h = (((ids * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)) >> np.uint64(16)) % np.uint64(G)
-        for g in range(0, G, max(1, G // 8)):
-            hit = (h == g).astype(np.int64)
-            csum = np.concatenate([[0], np.cumsum(hit)])
-            per_window = csum[window::window] - csum[:-window:window]
-            assert per_window.max() < K2_LIST, (G, g, int(per_window.max()))
+def test_k2_group_hash_is_balanced():
+    """sgc_part.hip K2: workgroup g of a slice takes the blocks whose id b has ((b * 0x9E3779B1) mod 2^32 >> 16) & (G-1)
+    == g.  Any assignment is correct (an overfull list is rescanned); this only checks the spread is even, so that
+    the G workgroups of a slice get equal shares."""
+    for G in (8, 16, 64, 512):
+        ids = np.arange(0, 1 << 18, dtype=np.uint64)
+        h = (((ids * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)) >> np.uint64(16)) & np.uint64(G - 1)
+        counts = np.bincount(h.astype(np.int64), minlength=G)
+        assert counts.max() < 1.1 * counts.mean() + 8 and counts.min() > 0.9 * counts.mean() - 8, (G, counts.min(), counts.max())
