@@ -222,3 +222,43 @@ def test_full_size_properties(env):
         ctr.feed_text(synth.fastq_host(wl.lib_seqs, first, 500_000))
     assert (cp.tolist(), tp, mp) == (ctr.table(), ctr.total_reads(), ctr.matched_reads())
     wl.close()
+
+
+def test_extreme_skew(env):
+    """Adversarial input: 40M reads of which 30M are ONE guide (one slice, one slot), 6M a single one-mismatch
+    variant of another guide, 4M one junk read.  Exercises K1's multi-block spills, K2's list overflow/rescan
+    path and same-address LDS atomics; the table must still be exact."""
+    import ctypes as C
+    torch, S, synth, workload = env
+    ffi = S._ffi
+    lib_seqs, library = workload.synth_library(100_000, 20)
+    g0, g1 = lib_seqs[4242].tobytes(), bytearray(lib_seqs[77].tobytes())
+    g1[7] = ord("A") if g1[7] != ord("A") else ord("C")
+    pre, tail = b"T" * 30, b"G" * 40
+    reads = [pre + g0 + tail, pre + bytes(g1) + tail, pre + b"ACGT" * 5 + tail]
+    mult = [30_000_000, 6_000_000, 4_000_000]
+    lib_text = synth.library_fasta(lib_seqs)
+    olib = O.Library(lib_text)
+    operm = O.Permuter(olib)
+    want = np.zeros(100_000, dtype=np.uint64)
+    matched = 0
+    for r, m in zip(reads, mult):
+        t = O.Counter(olib, operm, False, 30, 20, True).feed_seq(r).table()
+        want += np.array(t, dtype=np.uint64) * np.uint64(m)
+        matched += sum(t) * m
+    assert want[4242] == 30_000_000 and matched >= 30_000_000
+    recs = S.pack_reads_host(reads, 20, S.Offset.Forward(30), True)
+    d = torch.from_numpy(recs.view(np.int64)).cuda()
+    big = torch.repeat_interleave(d, torch.tensor(mult, device="cuda"))
+    big = big[torch.randperm(big.numel(), device="cuda")]          # interleave the three kinds
+    dl = library.device(True)
+    dl.set_stream(torch.cuda.current_stream().cuda_stream)
+    smp = C.c_void_p()
+    ffi.check(dl.lib.sgc_sample_begin(dl.ctx, C.byref(smp), 0, 30, 1))
+    ffi.check(dl.lib.sgc_sample_push_packed(smp, big.data_ptr(), big.numel(), ffi.MEM_DEVICE))
+    out = np.zeros(100_000, dtype=np.uint64)
+    t, m = C.c_uint64(), C.c_uint64()
+    ffi.check(dl.lib.sgc_sample_finish(smp, out.ctypes.data, C.byref(t), C.byref(m)))
+    dl.lib.sgc_sample_free(smp)
+    assert t.value == sum(mult) and m.value == matched
+    assert np.array_equal(out, want)
