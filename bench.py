@@ -77,22 +77,29 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(n_dev, 1)          # one rank per GPU on a full node; ranks share a card only in rehearsals
+    torch.cuda.set_device(dev_index)
+    backend = os.environ.get("SGC_BENCH_BACKEND", "nccl")   # "gloo": rehearse the N > 1 flow on a box with fewer GPUs
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
 
     L, offset, recursion = 20, 30, True
     exact = args.workload == "exact"
     wl = DeviceWorkload(args.reads, args.guides, L, one_mismatch=not exact, position_recursion=recursion, offset=offset,
-                        reads_seed=synth.READS_SEED + rank, device_index=local_rank)
+                        reads_seed=synth.READS_SEED + rank, device_index=dev_index)
     if args.variant is not None:
         wl.dl.set_option("variant", args.variant)
-    matrix = torch.zeros((world, args.guides + 2), dtype=torch.int64, device=wl.dev) if world > 1 else None
+    coll_dev = wl.dev if backend == "nccl" else torch.device("cpu")
+    matrix = torch.zeros((world, args.guides + 2), dtype=torch.int64, device=coll_dev) if world > 1 else None
 
     def step():
         wl.step()
-        if world > 1:
-            all_gather_rows(wl.export, matrix)   # per-sample count matrix over RCCL/xGMI
+        if world > 1:          # per-sample count matrix: one all-gather over RCCL/xGMI (gloo rehearsal: via the host)
+            all_gather_rows(wl.export if backend == "nccl" else wl.export.cpu(), matrix)
 
     def fence():
         torch.cuda.synchronize()
@@ -113,7 +120,7 @@ def main():
     tm = wl.dl.timing(reset=True)
     wl.dl.timing(False)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=wl.dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

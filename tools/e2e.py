@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""End-to-end timing of the sgcount-hip command line on a synthetic FASTQ file (page cache -> count table),
-next to the CPU oracle on the same file.  python tools/e2e.py --reads 5000000 [--gz]"""
+"""End-to-end timing of the sgcount-hip command line on a synthetic FASTQ file (page cache -> count table).
+python tools/e2e.py --reads 5000000   (the CPU baseline is timed by bench.py, the only place besides tests/ that may load the oracle)"""
 import argparse
 import gzip
 import os
@@ -10,7 +10,6 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
@@ -18,7 +17,6 @@ def main():
     ap.add_argument("--reads", type=int, default=5_000_000)
     ap.add_argument("--guides", type=int, default=100_000)
     ap.add_argument("--dir", default="/tmp/sgc_e2e")
-    ap.add_argument("--oracle-reads", type=int, default=1_000_000)
     args = ap.parse_args()
     from sgcount_amd import hostlib, synth
     os.makedirs(args.dir, exist_ok=True)
@@ -55,21 +53,6 @@ def main():
             label, best, args.reads / best / 1e6), flush=True)
     assert outs["plain, GPU-parsed FASTQ"] == outs["plain, host-parsed + GPU pack"] == outs["plain, host-parsed + host pack"] \
         == outs[".gz,   GPU-parsed FASTQ"]
-    # CPU oracle on a prefix of the same file (FASTQ text in, one thread)
-    import _oracle as O
-    lib_text = open(lib_path, "rb").read()
-    with open(fq, "rb") as f:
-        text = f.read(400 * args.oracle_reads)
-    text = text[: text.rindex(b"\n@r") + 1]
-    n = text.count(b"\n") // 4
-    olib = O.Library(lib_text)
-    t0 = time.time()
-    perm = O.Permuter(olib)
-    t_perm = time.time() - t0
-    t0 = time.time()
-    O.Counter(olib, perm, False, 30, 20, True).feed_text(text)
-    dt = time.time() - t0
-    print("CPU oracle (1 thread): %.1f M reads/s (+ %.1f s permuter build)" % (n / dt / 1e6, t_perm))
 
 
 if __name__ == "__main__":
