@@ -52,6 +52,7 @@ __global__ void __launch_bounds__(256) k_partition(const uint64_t *__restrict__ 
                                                    uint32_t log2_slice, uint64_t *__restrict__ pool,
                                                    uint32_t *__restrict__ desc) {
     __shared__ uint64_t stage[PART_TILE];
+    __shared__ uint8_t stage_p[PART_TILE];               // partition of every staged record
     __shared__ uint32_t cnt[PART_ARR], start[PART_ARR], blk[PART_ARR], fill[PART_ARR];
     __shared__ uint32_t dst_a[PART_ARR], dst_b[PART_ARR], split[PART_ARR];
     __shared__ uint32_t next_free;
@@ -130,12 +131,16 @@ __global__ void __launch_bounds__(256) k_partition(const uint64_t *__restrict__ 
 #pragma unroll
         for (uint32_t k = 0; k < PART_TILE / 256; k++) {
             const uint32_t j = k * 256 + t;
-            if (j < m) stage[start[pr[k] >> 16] + (pr[k] & 0xFFFFu)] = rec[k];
+            if (j < m) {
+                const uint32_t at = start[pr[k] >> 16] + (pr[k] & 0xFFFFu);
+                stage[at] = rec[k];
+                stage_p[at] = (uint8_t)(pr[k] >> 16);
+            }
         }
         __syncthreads();
         for (uint32_t j = t; j < m; j += 256) {
             const uint64_t r = stage[j];
-            const uint32_t p = part_of(r, kmask, sh, log2_slots, log2_slice);
+            const uint32_t p = stage_p[j];
             const uint32_t rank = j - start[p];
             const uint64_t at = rank < split[p] ? (uint64_t)dst_a[p] + rank : (uint64_t)dst_b[p] + (rank - split[p]);
             pool[at] = r;
