@@ -57,6 +57,7 @@ struct sgc_ctx {
     int variant = 3;            // count path variant: 0 direct atomics, 1/2 gid array + LDS histogram, 3 partitioned
     int per_lane = 4;           // records per lane in the v2 lookup kernel
     uint32_t dbg = 0;           // timing-only ablation flags (results are wrong when non-zero)
+    uint32_t k1_wgs = 256;      // workgroups of the partition kernel: few, so that few half-empty blocks are left open
     uint64_t max_chunk = 1ull << 27;   // records per internal pass (bounds the scratch buffers)
     // timing
     bool timing = false;
@@ -141,7 +142,7 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
         const uint64_t *p = d_recs + done * (c->rec16 ? 2 : 1);
         if (c->variant >= 3 && sgc_part_supported(c->v_lib, c->rec16)) {
             sgc_part_geometry g;
-            sgc_part_plan(chunk, c->v_lib, &g);
+            sgc_part_plan(chunk, c->v_lib, c->k1_wgs, &g);
             int rc = ensure(&c->d_pool, &c->pool_cap, g.pool_bytes);
             if (rc) return rc;
             rc = ensure(&c->d_desc, &c->desc_cap, g.desc_bytes);
@@ -296,6 +297,7 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
     if (!c || !key) return fail(SGC_E_ARG, "sgc_set_option: NULL argument");
     if (!strcmp(key, "variant")) { c->variant = (int)value; return SGC_OK; }
     if (!strcmp(key, "dbg")) { c->dbg = (uint32_t)value; return SGC_OK; }
+    if (!strcmp(key, "k1_wgs")) { c->k1_wgs = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 65536)); return SGC_OK; }
     if (!strcmp(key, "max_chunk")) {
         if (value < 1 || value > (int64_t)0xF0000000ll) return fail(SGC_E_ARG, "max_chunk out of range");
         c->max_chunk = (uint64_t)value; return SGC_OK;

@@ -41,7 +41,7 @@ struct sgc_part_geometry {
     uint64_t per_wg, pool_bytes, desc_bytes, gids_bytes;
 };
 bool sgc_part_supported(const sgc_table_view &lib, bool rec16);
-void sgc_part_plan(uint64_t n, const sgc_table_view &lib, sgc_part_geometry *g);
+void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_part_geometry *g);
 void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib,
                         const sgc_part_geometry &g, uint64_t *pool, uint32_t *desc);
 void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_part_geometry &g,

@@ -28,7 +28,10 @@
 #include "sgc_format.h"
 #include "sgc_kernels.h"
 
-#define PART_TILE 2048u          // records staged per tile in K1
+#ifndef K1_THREADS
+#define K1_THREADS 1024u        // one 16-wave workgroup per CU: few workgroups leave few half-empty blocks open
+#endif
+#define PART_TILE (K1_THREADS * 8u) // records staged per tile in K1 (8 per lane)
 #define PART_BLOCK 1024u         // records per block (small blocks: fewer empty slots in the open blocks K1 leaves)
 #define PART_MAXP 64u            // max library slices; partition index PART_MAXP' = P_lib is the generic one
 #define PART_ARR (PART_MAXP + 1u)
@@ -47,7 +50,7 @@ __device__ __forceinline__ uint32_t part_of(uint64_t rec, uint64_t kmask, uint32
 }
 
 // ------------------------------------------------------------------------------------------------ K1
-__global__ void __launch_bounds__(256) k_partition(const uint64_t *__restrict__ recs, uint64_t n, uint64_t per_wg,
+__global__ void __launch_bounds__(K1_THREADS) k_partition(const uint64_t *__restrict__ recs, uint64_t n, uint64_t per_wg,
                                                    uint32_t blocks_per_wg, uint32_t L, uint32_t log2_slots,
                                                    uint32_t log2_slice, uint64_t *__restrict__ pool,
                                                    uint32_t *__restrict__ desc) {
@@ -69,16 +72,16 @@ __global__ void __launch_bounds__(256) k_partition(const uint64_t *__restrict__ 
         const uint32_t m = (uint32_t)(hi - base < PART_TILE ? hi - base : PART_TILE);
         if (t < PART_ARR) cnt[t] = 0;
         __syncthreads();
-        uint64_t rec[PART_TILE / 256];
-        uint32_t pr[PART_TILE / 256];     // partition << 16 | rank inside the tile
+        uint64_t rec[PART_TILE / K1_THREADS];
+        uint32_t pr[PART_TILE / K1_THREADS];     // partition << 16 | rank inside the tile
 #pragma unroll
-        for (uint32_t k = 0; k < PART_TILE / 256; k++) {
-            const uint32_t j = k * 256 + t;
+        for (uint32_t k = 0; k < PART_TILE / K1_THREADS; k++) {
+            const uint32_t j = k * K1_THREADS + t;
             if (j < m) rec[k] = __builtin_nontemporal_load(&recs[base + j]);
         }
 #pragma unroll
-        for (uint32_t k = 0; k < PART_TILE / 256; k++) {
-            const uint32_t j = k * 256 + t;
+        for (uint32_t k = 0; k < PART_TILE / K1_THREADS; k++) {
+            const uint32_t j = k * K1_THREADS + t;
             if (j < m) {
                 const uint32_t p = part_of(rec[k], kmask, sh, log2_slots, log2_slice);
                 pr[k] = (p << 16) | atomicAdd(&cnt[p], 1u);
@@ -129,8 +132,8 @@ __global__ void __launch_bounds__(256) k_partition(const uint64_t *__restrict__ 
         }
         __syncthreads();
 #pragma unroll
-        for (uint32_t k = 0; k < PART_TILE / 256; k++) {
-            const uint32_t j = k * 256 + t;
+        for (uint32_t k = 0; k < PART_TILE / K1_THREADS; k++) {
+            const uint32_t j = k * K1_THREADS + t;
             if (j < m) {
                 const uint32_t at = start[pr[k] >> 16] + (pr[k] & 0xFFFFu);
                 stage[at] = rec[k];
@@ -138,7 +141,7 @@ __global__ void __launch_bounds__(256) k_partition(const uint64_t *__restrict__ 
             }
         }
         __syncthreads();
-        for (uint32_t j = t; j < m; j += 256) {
+        for (uint32_t j = t; j < m; j += K1_THREADS) {
             const uint64_t r = stage[j];
             const uint32_t p = stage_p[j];
             const uint32_t rank = j - start[p];
@@ -556,10 +559,11 @@ bool sgc_part_supported(const sgc_table_view &lib, bool rec16) {
     return (lib.log2_slots - lib.log2_slice) <= 6;      // <= PART_MAXP partitions
 }
 
-void sgc_part_plan(uint64_t n, const sgc_table_view &lib, sgc_part_geometry *g) {
+void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_part_geometry *g) {
     const uint32_t P = 1u << (lib.log2_slots - lib.log2_slice);
     uint64_t tiles = (n + PART_TILE - 1) / PART_TILE;
-    uint32_t wgs = (uint32_t)(tiles < 1024 ? (tiles ? tiles : 1) : 1024);
+    if (max_wgs == 0) max_wgs = 256;
+    uint32_t wgs = (uint32_t)(tiles < max_wgs ? (tiles ? tiles : 1) : max_wgs);
     uint64_t per = (tiles + wgs - 1) / wgs * PART_TILE;                 // records per K1 workgroup, whole tiles
     g->k1_wgs = wgs;
     g->per_wg = per;
@@ -575,7 +579,7 @@ void sgc_part_plan(uint64_t n, const sgc_table_view &lib, sgc_part_geometry *g) 
 void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib,
                         const sgc_part_geometry &g, uint64_t *pool, uint32_t *desc) {
     (void)hipMemsetAsync(desc, 0, g.desc_bytes, st);
-    hipLaunchKernelGGL(k_partition, dim3(g.k1_wgs), dim3(256), 0, st, recs, n, g.per_wg, g.blocks_per_wg, L,
+    hipLaunchKernelGGL(k_partition, dim3(g.k1_wgs), dim3(K1_THREADS), 0, st, recs, n, g.per_wg, g.blocks_per_wg, L,
                        lib.log2_slots, lib.log2_slice, pool, desc);
 }
 
