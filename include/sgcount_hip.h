@@ -12,7 +12,10 @@
  * INTEGRATION.md shows the Rust `extern "C"` block a maintainer would add to
  * bind them.  Conventions: 0 = OK, negative = error (sgc_last_error() holds a
  * thread-local message); no exceptions or aborts cross the ABI; every buffer
- * is caller-owned; plain pointers and sizes only.
+ * is caller-owned; plain pointers and sizes only.  Threading: the tables of a ctx are
+ * read-only and shared, but its stream and scratch buffers are not — drive one ctx
+ * (and its samples) from one thread at a time; use one ctx per device and per
+ * concurrent host thread (the C++ host does: sgcount_amd/csrc/host/sgh.cpp count()).
  *
  * Division of labour (BASELINE.json north_star): the host streams FASTQ and
  * 2-bit-packs each read's guide window into one record (sgc_pack_reads_host,

@@ -115,3 +115,41 @@ def fastx_stats(path):
     a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
     _chk(load().sgh_fastx_stats(path.encode(), C.byref(a), C.byref(b), C.byref(c)))
     return a.value, b.value, c.value
+
+
+def cli(argv):
+    """Runs the sgcount-hip command line in-process (sgh::cli_main); returns its exit code (0 ok, 1 error,
+    101 panic, 2 usage)."""
+    args = [b"sgcount-hip"] + [a.encode() if isinstance(a, str) else a for a in argv]
+    arr = (C.c_char_p * len(args))(*args)
+    return load().sgh_cli(len(args), arr)
+
+
+def count(library_path, input_paths, sample_names=None, output_path=None, offset=None, exact=False, genemap=None,
+          position_recursion=True, include_zero=False, quiet=True, reverse=False, threads=1, subsample=None):
+    """count() of the reference (src/count.rs:74-148) with main()'s option handling (src/main.rs:142-203):
+    offset = None → entropy auto-offset; an int → Forward(offset) (Reverse if reverse=True)."""
+    argv = ["-l", library_path, "-i", *input_paths, "-t", str(threads)]
+    if sample_names:
+        argv += ["-n", *sample_names]
+    if output_path:
+        argv += ["-o", output_path]
+    if offset is not None:
+        argv += ["-a", str(int(offset))]
+    if reverse:
+        argv.append("-r")
+    if exact:
+        argv.append("-x")
+    if genemap:
+        argv += ["-g", genemap]
+    if not position_recursion:
+        argv.append("-p")
+    if include_zero:
+        argv.append("-z")
+    if quiet:
+        argv.append("-q")
+    if subsample is not None:
+        argv += ["-s", str(int(subsample))]
+    rc = cli(argv)
+    if rc:
+        raise HostError(rc, "sgcount-hip exited with code %d" % rc)

@@ -114,3 +114,17 @@ def test_error_paths(cli, tmp_path):
     assert code == 1 and "outside ACGT" in err                                        # no CPU fallback: fails loudly
     code, out, _ = run(cli, "--help")
     assert code == 0 and "--library-path" in out and "--no-position-recursion" in out
+
+
+def test_python_count_wrapper(tmp_path, example_library_text, example_reads):
+    """sgcount_amd.hostlib.count(): the reference's count() signature over the in-process CLI."""
+    from sgcount_amd import hostlib
+    outp = os.path.join(str(tmp_path), "t.tsv")
+    hostlib.count(LIB, [os.path.join(DATA, "sequence.fastq.gz"), os.path.join(DATA, "zero.sequence.fastq.gz")],
+                  sample_names=["a", "b"], output_path=outp, offset=5, exact=False, include_zero=True)
+    want = oracle_table(example_library_text, [example_reads["sequence"], example_reads["zero.sequence"]], ["a", "b"],
+                        [(False, 5)] * 2, False, True, None, True)
+    assert open(outp).read() == want
+    with pytest.raises(hostlib.HostError) as e:
+        hostlib.count(LIB, [os.path.join(str(tmp_path), "missing.fq")], offset=5)
+    assert e.value.code == 101
