@@ -46,6 +46,14 @@ struct sgc_ctx {
     uint64_t *d_bloom_lib = nullptr, *d_bloom_perm = nullptr;
     sgc_bloom_view b_lib{}, b_perm{};
     uint64_t perm_entries = 0;
+    // core indexes + ambiguity masks of the in-LDS single-mismatch resolver (variant 4; sgc_core.hip)
+    bool has_core = false;
+    uint64_t *d_core_ents[2] = {nullptr, nullptr}, *d_amb = nullptr;
+    uint32_t *d_core_gids[2] = {nullptr, nullptr};
+    uint16_t *d_core_starts[2] = {nullptr, nullptr};
+    sgc_core_view v_core[2] = {};
+    void *d_cbuf = nullptr; size_t cbuf_cap = 0;        // two record buffers of the core passes
+    void *d_csmall = nullptr; size_t csmall_cap = 0;    // their histograms / partition starts / extents
     // scratch (grown on demand, stream-ordered reuse)
     void *d_stage = nullptr; size_t stage_cap = 0;      // host -> device staging of pushed buffers
     void *d_aux = nullptr; size_t aux_cap = 0;          // offsets / secondary staging
@@ -54,7 +62,8 @@ struct sgc_ctx {
     void *d_pool = nullptr; size_t pool_cap = 0;        // partitioned path: record blocks
     void *d_desc = nullptr; size_t desc_cap = 0;        // partitioned path: block descriptors
     // options
-    int variant = 3;            // count path variant: 0 direct atomics, 1/2 gid array + LDS histogram, 3 partitioned
+    int variant = 4;            // count path variant: 0 direct atomics, 1/2 gid array + LDS histogram,
+                                // 3 partitioned + probing miss resolver, 4 partitioned + in-LDS core resolver
     int per_lane = 4;           // records per lane in the v2 lookup kernel
     uint32_t dbg = 0;           // timing-only ablation flags (results are wrong when non-zero)
     uint32_t k1_wgs = 256;      // workgroups of the partition kernel: few, so that few half-empty blocks are left open
@@ -151,6 +160,24 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
             uint32_t *desc = (uint32_t *)c->d_desc;
             { timed t(c, T_PART); sgc_launch_part_k1(c->stream, p, chunk, c->L, c->v_lib, g, pool, desc); }
             { timed t(c, T_LOOKUP); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg); }
+            if (c->variant >= 4 && c->one_mm && c->has_core) {
+                // everything K2 did not settle (its misses + the generic partition) is resolved in LDS
+                sgc_core_geometry cg;
+                sgc_core_plan(chunk, c->v_core[0], c->v_core[1], &cg);
+                rc = ensure(&c->d_cbuf, &c->cbuf_cap, (size_t)cg.recs_bytes * 2);
+                if (rc) return rc;
+                rc = ensure(&c->d_csmall, &c->csmall_cap, cg.small_bytes);
+                if (rc) return rc;
+                timed t(c, T_MISS);
+                sgc_launch_core(c->stream, c->L, c->v_lib, c->v_perm, c->v_core[0], c->v_core[1], c->d_amb, cg, pool, desc,
+                                g.n_blocks, g.block_records, (uint64_t *)c->d_cbuf, (uint64_t *)c->d_cbuf + chunk,
+                                c->d_csmall, s->d_c32, s->d_matched, c->dbg);
+                HIP_TRY(hipGetLastError());
+                done += chunk;
+                s->since_fold += chunk;
+                if (done < n) { sgc_launch_fold(c->stream, s->d_c32, s->d_c64, c->n); s->since_fold = 0; }
+                continue;
+            }
             rc = ensure(&c->d_gids, &c->gids_cap, g.gids_bytes);                // one slot per pool record: every read may miss
             if (rc) return rc;
             rc = ensure(&c->d_aux, &c->aux_cap, ((size_t)g.n_segs + 1) * 4);
@@ -249,6 +276,14 @@ static void free_tables(sgc_ctx *c) {
     if (c->d_bloom_lib) hipFree(c->d_bloom_lib);
     if (c->d_bloom_perm) hipFree(c->d_bloom_perm);
     c->d_bloom_lib = c->d_bloom_perm = nullptr;
+    for (int k = 0; k < 2; k++) {
+        if (c->d_core_ents[k]) hipFree(c->d_core_ents[k]);
+        if (c->d_core_gids[k]) hipFree(c->d_core_gids[k]);
+        if (c->d_core_starts[k]) hipFree(c->d_core_starts[k]);
+        c->d_core_ents[k] = nullptr; c->d_core_gids[k] = nullptr; c->d_core_starts[k] = nullptr; c->v_core[k] = sgc_core_view{};
+    }
+    if (c->d_amb) hipFree(c->d_amb);
+    c->d_amb = nullptr; c->has_core = false;
     c->b_lib = sgc_bloom_view{}; c->b_perm = sgc_bloom_view{};
     c->d_lib_slots = c->d_perm_slots = nullptr;
     c->d_lib_vals = c->d_perm_vals = nullptr;
@@ -268,6 +303,8 @@ void sgc_free(sgc_ctx *c) {
     if (c->d_gids) hipFree(c->d_gids);
     if (c->d_pool) hipFree(c->d_pool);
     if (c->d_desc) hipFree(c->d_desc);
+    if (c->d_cbuf) hipFree(c->d_cbuf);
+    if (c->d_csmall) hipFree(c->d_csmall);
     if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
@@ -352,8 +389,29 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
     c->v_perm = sgc_table_view{nullptr, nullptr, 0, h_lib.gid_bits, 0, 0};
     c->perm_entries = 0;
     if (enable_1mm) {
-        std::vector<uint64_t> child_keys;
-        sgc_build_permute_table(keys, L, h_lib, h_perm, &child_keys);
+        std::vector<uint64_t> child_keys, amb;
+        sgc_build_permute_table(keys, L, h_lib, h_perm, &child_keys, &amb);
+        // core indexes (variant 4): span bases [2, L) cut in two; absent => the probing resolver stays in charge
+        if (L >= 4 && L <= SGC_REC8_MAXL && h_lib.gid_bits != 0) {
+            const uint32_t ca = (L - 2) / 2;
+            sgc_host_core hc[2];
+            if (sgc_build_core_index(keys, L, 2, ca, hc[0]) && sgc_build_core_index(keys, L, 2 + ca, L - 2 - ca, hc[1])) {
+                for (int k = 0; k < 2; k++) {
+                    HIP_TRY(hipMalloc((void **)&c->d_core_ents[k], hc[k].ents.size() * 8));
+                    HIP_TRY(hipMalloc((void **)&c->d_core_gids[k], hc[k].gids.size() * 4));
+                    HIP_TRY(hipMalloc((void **)&c->d_core_starts[k], hc[k].starts.size() * 2));
+                    HIP_TRY(hipMemcpyAsync(c->d_core_ents[k], hc[k].ents.data(), hc[k].ents.size() * 8, hipMemcpyHostToDevice, c->stream));
+                    HIP_TRY(hipMemcpyAsync(c->d_core_gids[k], hc[k].gids.data(), hc[k].gids.size() * 4, hipMemcpyHostToDevice, c->stream));
+                    HIP_TRY(hipMemcpyAsync(c->d_core_starts[k], hc[k].starts.data(), hc[k].starts.size() * 2, hipMemcpyHostToDevice, c->stream));
+                    c->v_core[k] = sgc_core_view{c->d_core_ents[k], c->d_core_gids[k], c->d_core_starts[k], hc[k].log2_p, hc[k].cs, hc[k].cl, 0};
+                }
+                HIP_TRY(hipMalloc((void **)&c->d_amb, amb.size() * 8));
+                HIP_TRY(hipMemcpyAsync(c->d_amb, amb.data(), amb.size() * 8, hipMemcpyHostToDevice, c->stream));
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                c->has_core = true;
+                if (getenv("SGC_OCC_DBG")) sgc_core_print_occupancy();
+            }
+        }
         rc = upload_table(h_perm, &c->d_perm_slots, &c->d_perm_vals, &c->v_perm, c->stream);
         if (rc != SGC_OK) { free_tables(c); return rc; }
         c->perm_entries = h_perm.entries;

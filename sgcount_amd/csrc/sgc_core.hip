@@ -1,0 +1,483 @@
+// sgc_core.hip — single-mismatch resolution in LDS (count path variant 4), gfx950.
+//
+// k_resolve_miss (sgc_part.hip) answers "is this window one substitution away from exactly one guide?"
+// (Permuter, reference src/permutes.rs:63-158) with gathers into a ~100 MB child -> parent table, and every
+// such gather leaves the L2.  This file answers the same question inside LDS:
+//
+//   Span bases [2, L) lie inside all three windows (M = span[0, L), C = span[1, L+1), P = span[2, L+2)).
+//   Cut them into two disjoint CORES, A = [2, 2+a) and B = [2+a, L).  A window that is within one
+//   substitution of a guide agrees with it on core A or on core B (or both).  So: partition the unresolved
+//   records by the hash of their core-A bases; a workgroup stages the guides whose core-A bases (at each of
+//   the three alignments) hash to its partition — a few thousand 8-byte entries — and every record meets,
+//   in one short probe chain, ALL guides that agree with any of its windows on core A.  XOR + popcount
+//   gives the Hamming distance: 0 = exact (src/counter.rs:111), 1 = a parent of the window's child
+//   (src/counter.rs:113-116).  What pass A cannot see (a substitution inside core A) pass B sees, the same
+//   kernel over core B.
+//
+//   Uniqueness (src/permutes.rs:127-144: a child with two parents maps to nothing): the parents whose
+//   substitution lies outside the pass's core all sit in the chain and are counted; a parent with its
+//   substitution inside the core is invisible, so for a single visible parent one bit of a per-guide mask
+//   (sgc_tables.cpp: amb, bit 4j+b = "child (j, b) of this guide has another parent") decides.  A window
+//   with an 'N' at j needs no mask: it is resolved by the pass whose core does not hold j, where every
+//   guide that agrees on all other positions is in the chain.
+//
+//   Order (src/counter.rs:111-135): C-exact, C-1mm, P-exact, P-1mm, M-exact, M-1mm.  Pass A takes the first
+//   level it can prove; if a higher single-mismatch level is still undecided (nothing seen in A) the
+//   record goes on to pass B, which sees everything pass A could not, plus every exact level again.  The
+//   rare "1mm found at P/M in pass A, C-1mm undecided" case is closed on the spot with the global tables.
+//
+// Kernels: k_cp_hist / k_cp_scan / k_cp_scatter (two-pass counting partition of record *extents* into
+// contiguous per-partition ranges, LDS-staged so that the writes are runs) and k_core (the resolver).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "sgc_device.h"
+#include "sgc_format.h"
+#include "sgc_kernels.h"
+
+#define CP_THREADS 1024u
+#define CP_W 256u                // workgroups of the partition kernels
+#define CP_TILE 8192u
+#define CP_SEG 1024u             // extents scanned per segment
+#define CP_MAXP (1u << SGC_CORE_MAX_LOG2_P)
+#define CP_DROP 0xFFFFu
+#define KC_THREADS 1024u
+#define KC_CHUNK 4096u           // records per unit of resolver work
+#define KC_GRID 512u
+
+// Partition of a record, or CP_DROP for a record whose three windows are all dead (a read too short for the
+// Centered window, src/counter.rs:158-166): it cannot match, and all such records are identical, so they
+// would pile up in one partition.
+__device__ __forceinline__ uint32_t cp_part(uint64_t rec, uint32_t cs2, uint64_t cmask, uint32_t log2_p, uint32_t sh,
+                                            uint32_t dead_all) {
+    if ((uint32_t)(rec >> sh) == dead_all) return CP_DROP;
+    return sgc_core_part(sgc_hash((rec >> cs2) & cmask), log2_p);
+}
+
+// exclusive scan of one value per thread over a 1024-thread workgroup; returns the prefix, *total = sum
+__device__ __forceinline__ uint32_t wg_scan_1024(uint32_t v, uint32_t *wsum /*[17] in LDS*/, uint32_t *total) {
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t x = __shfl_up(incl, off, 64);
+        if ((int)lane >= off) incl += x;
+    }
+    __syncthreads();                       // wsum may still be read from a previous call
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (uint32_t w = 0; w < 16; w++) { const uint32_t x = wsum[w]; wsum[w] = run; run += x; }
+        wsum[16] = run;
+    }
+    __syncthreads();
+    *total = wsum[16];
+    return wsum[wave] + incl - v;
+}
+
+// last u in [0, ns) with off[u] <= d (entries with nothing in them share their offset with the next one)
+__device__ __forceinline__ uint32_t find_extent(const uint32_t *off, uint32_t ns, uint32_t d) {
+    uint32_t lo = 0, hi = ns;            // invariant: off[lo] <= d, answer in [lo, hi)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= d) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------------------ partition
+// Input: E extents of records; extent e holds (ext_cnt[e] & cnt_mask) records starting at record index
+// ext_off[e] (or e * stride when ext_off is NULL — the blocks of the slice-partitioned pool).  Workgroup w
+// owns extents [w * per, (w + 1) * per); a segment of extents is walked as one flat range of records.
+struct cp_args {
+    const uint64_t *in;
+    const uint32_t *ext_off, *ext_cnt;
+    uint32_t cnt_mask, stride, E, per, cs2, log2_p, sh, dead_all;
+    uint64_t cmask;
+};
+
+__global__ void __launch_bounds__(CP_THREADS) k_cp_hist(cp_args a, uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[CP_MAXP], off_[CP_SEG], wsum[17];
+    const uint32_t t = threadIdx.x, P = 1u << a.log2_p;
+    const uint32_t e0 = blockIdx.x * a.per, e1 = e0 + a.per < a.E ? e0 + a.per : a.E;
+    if (t < CP_MAXP) h[t] = 0;
+    for (uint32_t s0 = e0; s0 < e1; s0 += CP_SEG) {
+        const uint32_t ns = e1 - s0 < CP_SEG ? e1 - s0 : CP_SEG;
+        const uint32_t c = t < ns ? (a.ext_cnt[s0 + t] & a.cnt_mask) : 0;
+        uint32_t T;
+        off_[t] = wg_scan_1024(c, wsum, &T);
+        __syncthreads();
+        for (uint32_t r0 = 0; r0 < T; r0 += CP_TILE) {
+            uint64_t rec[CP_TILE / CP_THREADS];
+#pragma unroll
+            for (uint32_t k = 0; k < CP_TILE / CP_THREADS; k++) {       // all loads first: they overlap
+                const uint32_t d = r0 + k * CP_THREADS + t;
+                if (d < T) {
+                    const uint32_t u = find_extent(off_, ns, d);
+                    rec[k] = a.in[(a.ext_off ? (uint64_t)a.ext_off[s0 + u] : (uint64_t)(s0 + u) * a.stride) + (d - off_[u])];
+                }
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < CP_TILE / CP_THREADS; k++) {
+                const uint32_t d = r0 + k * CP_THREADS + t;
+                if (d < T) {
+                    const uint32_t p = cp_part(rec[k], a.cs2, a.cmask, a.log2_p, a.sh, a.dead_all);
+                    if (p != CP_DROP) atomicAdd(&h[p], 1u);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (t < P) hist[t * CP_W + blockIdx.x] = h[t];
+}
+
+// hist[P][CP_W] -> per-row exclusive prefix in place; pstart[p] = first record of partition p (pstart[P] =
+// total), cstart[p] = first KC_CHUNK-record chunk of partition p (cstart[P] = number of chunks)
+__global__ void __launch_bounds__(CP_THREADS) k_cp_scan(uint32_t *__restrict__ hist, uint32_t P, uint32_t *__restrict__ pstart,
+                                                        uint32_t *__restrict__ cstart) {
+    __shared__ uint32_t rowtot[CP_MAXP], wsum[17];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    constexpr uint32_t RW = CP_MAXP / 16, CW = CP_W / 64;               // rows per wave, 64-wide pieces per row
+    uint32_t x[RW][CW];
+#pragma unroll
+    for (uint32_t r = 0; r < RW; r++)
+#pragma unroll
+        for (uint32_t k = 0; k < CW; k++) {
+            const uint32_t p = wave + 16 * r;
+            x[r][k] = p < P ? hist[p * CP_W + k * 64 + lane] : 0;
+        }
+#pragma unroll
+    for (uint32_t r = 0; r < RW; r++) {
+        const uint32_t p = wave + 16 * r;
+        uint32_t run = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < CW; k++) {
+            uint32_t incl = x[r][k];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t y = __shfl_up(incl, off, 64);
+                if ((int)lane >= off) incl += y;
+            }
+            if (p < P) hist[p * CP_W + k * 64 + lane] = run + incl - x[r][k];
+            run += __shfl(incl, 63, 64);
+        }
+        if (lane == 0 && p < CP_MAXP) rowtot[p] = run;
+    }
+    __syncthreads();
+    const uint32_t n = t < P ? rowtot[t] : 0;
+    uint32_t total, ctotal;
+    const uint32_t pre = wg_scan_1024(n, wsum, &total);
+    const uint32_t cpre = wg_scan_1024((n + KC_CHUNK - 1) / KC_CHUNK, wsum, &ctotal);
+    if (t < P) { pstart[t] = pre; cstart[t] = cpre; }
+    if (t == 0) { pstart[P] = total; cstart[P] = ctotal; }
+}
+
+__global__ void __launch_bounds__(CP_THREADS) k_cp_scatter(cp_args a, const uint32_t *__restrict__ base,
+                                                           const uint32_t *__restrict__ pstart, uint64_t *__restrict__ out) {
+    __shared__ uint64_t stage[CP_TILE];
+    __shared__ uint8_t stage_p[CP_TILE];
+    __shared__ uint32_t cnt[CP_MAXP], start[CP_MAXP], cur[CP_MAXP];
+    __shared__ uint32_t off_[CP_SEG], wsum[17];
+    const uint32_t t = threadIdx.x, P = 1u << a.log2_p;
+    const uint32_t e0 = blockIdx.x * a.per, e1 = e0 + a.per < a.E ? e0 + a.per : a.E;
+    if (t < P) cur[t] = pstart[t] + base[t * CP_W + blockIdx.x];
+    for (uint32_t s0 = e0; s0 < e1; s0 += CP_SEG) {
+        const uint32_t ns = e1 - s0 < CP_SEG ? e1 - s0 : CP_SEG;
+        const uint32_t c = t < ns ? (a.ext_cnt[s0 + t] & a.cnt_mask) : 0;
+        uint32_t T;
+        off_[t] = wg_scan_1024(c, wsum, &T);
+        __syncthreads();
+        for (uint32_t r0 = 0; r0 < T; r0 += CP_TILE) {
+            const uint32_t m = T - r0 < CP_TILE ? T - r0 : CP_TILE;
+            if (t < CP_MAXP) cnt[t] = 0;
+            __syncthreads();
+            uint64_t rec[CP_TILE / CP_THREADS];
+            uint32_t pr[CP_TILE / CP_THREADS];
+#pragma unroll
+            for (uint32_t k = 0; k < CP_TILE / CP_THREADS; k++) {
+                const uint32_t j = k * CP_THREADS + t;
+                if (j < m) {
+                    const uint32_t d = r0 + j, u = find_extent(off_, ns, d);
+                    rec[k] = a.in[(a.ext_off ? (uint64_t)a.ext_off[s0 + u] : (uint64_t)(s0 + u) * a.stride) + (d - off_[u])];
+                }
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < CP_TILE / CP_THREADS; k++) {
+                const uint32_t j = k * CP_THREADS + t;
+                pr[k] = 0xFFFFFFFFu;
+                if (j < m) {
+                    const uint32_t p = cp_part(rec[k], a.cs2, a.cmask, a.log2_p, a.sh, a.dead_all);
+                    if (p != CP_DROP) pr[k] = (p << 16) | atomicAdd(&cnt[p], 1u);
+                }
+            }
+            __syncthreads();
+            uint32_t kept;
+            {
+                const uint32_t cc = t < P ? cnt[t] : 0;
+                const uint32_t st0 = wg_scan_1024(cc, wsum, &kept);
+                if (t < P) start[t] = st0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t k = 0; k < CP_TILE / CP_THREADS; k++) {
+                if (pr[k] != 0xFFFFFFFFu) {
+                    const uint32_t at = start[pr[k] >> 16] + (pr[k] & 0xFFFFu);
+                    stage[at] = rec[k];
+                    stage_p[at] = (uint8_t)(pr[k] >> 16);
+                }
+            }
+            __syncthreads();
+            for (uint32_t j = t; j < kept; j += CP_THREADS) {
+                const uint32_t p = stage_p[j];
+                out[(uint64_t)cur[p] + (j - start[p])] = stage[j];
+            }
+            __syncthreads();
+            if (t < P) cur[t] += cnt[t];
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ resolver
+// The partitioned records are cut into chunks of KC_CHUNK (never across a partition boundary); workgroup w of
+// KC_GRID takes the w-th equal share of the chunk list — a run of consecutive chunks, so it stages a new
+// partition's table only when its run crosses into the next partition, and a partition swollen by identical
+// reads is shared by as many workgroups as it has chunks.
+// FINAL = false (pass A): records with an undecided higher level are written to fwd[], from the start of the
+// workgroup's run (ext_off/ext_cnt[workgroup] describe what was written).  FINAL = true (pass B): undecided = no.
+template <bool FINAL>
+__global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(80))) k_core(
+    const uint64_t *__restrict__ in, const uint32_t *__restrict__ pstart, const uint32_t *__restrict__ cstart, sgc_core_view cv,
+    const ulonglong2 *__restrict__ amb, uint32_t L, sgc_table_view lib, sgc_table_view perm, uint64_t *__restrict__ fwd,
+    uint32_t *__restrict__ ext_off, uint32_t *__restrict__ ext_cnt, uint32_t *__restrict__ counts,
+    unsigned long long *__restrict__ matched, uint32_t dbg) {
+    __shared__ uint64_t ent[SGC_CORE_EMAX];
+    __shared__ uint32_t tgid[SGC_CORE_EMAX], cnt[SGC_CORE_EMAX];
+    __shared__ uint16_t start[SGC_CORE_STARTS];
+    __shared__ uint32_t ps[CP_MAXP + 1], cs_[CP_MAXP + 1];
+    __shared__ uint32_t n_fwd;
+    __shared__ unsigned long long wsum;
+    const uint32_t t = threadIdx.x, P = 1u << cv.log2_p;
+    if (t <= P) { ps[t] = pstart[t]; cs_[t] = cstart[t]; }
+    if (t == 0) { n_fwd = 0; wsum = 0; }
+    __syncthreads();
+    const uint32_t C = cs_[P];
+    const uint32_t c_lo = (uint32_t)((uint64_t)blockIdx.x * C / gridDim.x), c_hi = (uint32_t)((uint64_t)(blockIdx.x + 1) * C / gridDim.x);
+    const uint32_t K = L + 2, sh = 2 * K, cs2 = 2 * cv.cs, cl = cv.cl;
+    const uint64_t smask = (1ull << sh) - 1ull, kmask = sgc_key_mask(L), cmask = (1ull << (2 * cl)) - 1ull;
+    // window a (0 = M, 1 = C, 2 = P) starts at span base a: its core sits at window positions [ll_a, ll_a + cl)
+    const uint32_t ll0 = cv.cs, ll1 = cv.cs - 1, ll2 = cv.cs - 2;
+    const uint32_t hs2 = 2 * (cv.cs + cl);                  // span bit where the bases above the core start
+    const uint32_t hm = (uint32_t)((1ull << (2 * (L - cl))) - 1ull);   // a rest has L - cl bases
+    uint32_t local = 0, cur_p = 0xFFFFFFFFu, wlo = 0;
+    for (uint32_t ch = c_lo; ch < c_hi; ch++) {
+        const uint32_t p = find_extent(cs_, P, ch);
+        if (p != cur_p) {                                    // uniform over the workgroup
+            __syncthreads();
+            if (cur_p != 0xFFFFFFFFu && !(dbg & 8192))
+                for (uint32_t i = t; i < SGC_CORE_EMAX; i += KC_THREADS) {
+                    const uint32_t v = cnt[i];
+                    if (v) atomicAdd(&counts[tgid[i]], v);
+                }
+            __syncthreads();
+            const uint64_t *ge = cv.ents + (size_t)p * SGC_CORE_EMAX;
+            const uint32_t *gg = cv.gids + (size_t)p * SGC_CORE_EMAX;
+            const uint32_t *gs = reinterpret_cast<const uint32_t *>(cv.starts + (size_t)p * SGC_CORE_STARTS);
+            for (uint32_t i = t; i < SGC_CORE_EMAX; i += KC_THREADS) { ent[i] = ge[i]; tgid[i] = gg[i]; cnt[i] = 0; }
+            for (uint32_t i = t; i < SGC_CORE_STARTS / 2; i += KC_THREADS) reinterpret_cast<uint32_t *>(start)[i] = gs[i];
+            __syncthreads();
+            cur_p = p;
+        }
+        const uint32_t lo = ps[p] + (ch - cs_[p]) * KC_CHUNK, hi = lo + KC_CHUNK < ps[p + 1] ? lo + KC_CHUNK : ps[p + 1];
+        if (ch == c_lo) wlo = lo;
+        // the chunk's records first (KC_CHUNK / KC_THREADS loads in flight), then one at a time
+        uint64_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        static_assert(KC_CHUNK == 4 * KC_THREADS, "the register queue below holds four records");
+        if (lo + t < hi) r0 = __builtin_nontemporal_load(&in[lo + t]);
+        if (lo + KC_THREADS + t < hi) r1 = __builtin_nontemporal_load(&in[lo + KC_THREADS + t]);
+        if (lo + 2 * KC_THREADS + t < hi) r2 = __builtin_nontemporal_load(&in[lo + 2 * KC_THREADS + t]);
+        if (lo + 3 * KC_THREADS + t < hi) r3 = __builtin_nontemporal_load(&in[lo + 3 * KC_THREADS + t]);
+#pragma unroll 1
+        for (uint32_t i0 = lo; i0 < hi; i0 += KC_THREADS) {
+            const bool valid = i0 + t < hi;
+            const uint64_t rec = r0;
+            r0 = r1; r1 = r2; r2 = r3;
+            const uint64_t span = rec & smask;
+            const uint32_t status = (uint32_t)(rec >> sh);
+            const uint32_t corev = (uint32_t)((span >> cs2) & cmask);
+            // the rests of the three windows: bases below the core | bases above it
+            const uint32_t hi_bits = (uint32_t)(span >> hs2);
+            const uint32_t R0 = ((uint32_t)span & ((1u << (2 * ll0)) - 1u)) | ((hi_bits << (2 * ll0)) & hm);
+            const uint32_t R1 = ((uint32_t)(span >> 2) & ((1u << (2 * ll1)) - 1u)) | ((hi_bits << (2 * ll1)) & hm);
+            const uint32_t R2 = ((uint32_t)(span >> 4) & ((1u << (2 * ll2)) - 1u)) | (hi_bits << (2 * ll2));
+            // vis bit a: window a takes part in this pass; unk bit a: its single-mismatch level cannot be decided
+            // here ('N' inside the core); nr_a: the 'N' position as a bit of the rest (0 = clean)
+            uint32_t vis = valid ? 7u : 0u, unk = 0, nr0 = 0, nr1 = 0, nr2 = 0, st0 = 0, st1 = 0, st2 = 0;
+            if (status) {
+                st1 = status % K; st2 = (status / K) % K; st0 = status / (K * K);
+                if (st0 == SGC_STATE_DEAD) vis &= ~1u;
+                if (st1 == SGC_STATE_DEAD) vis &= ~2u;
+                if (st2 == SGC_STATE_DEAD) vis &= ~4u;
+                if (st0 >= 2) { const uint32_t j = st0 - 2; if (j >= ll0 && j < ll0 + cl) { vis &= ~1u; unk |= 1u; } else nr0 = 1u << (2 * (j < ll0 ? j : j - cl)); }
+                if (st1 >= 2) { const uint32_t j = st1 - 2; if (j >= ll1 && j < ll1 + cl) { vis &= ~2u; unk |= 2u; } else nr1 = 1u << (2 * (j < ll1 ? j : j - cl)); }
+                if (st2 >= 2) { const uint32_t j = st2 - 2; if (j >= ll2 && j < ll2 + cl) { vis &= ~4u; unk |= 4u; } else nr2 = 1u << (2 * (j < ll2 ? j : j - cl)); }
+            }
+            uint32_t ex0 = SGC_NONE, ex1 = SGC_NONE, ex2 = SGC_NONE;      // entry of the exact guide
+            uint32_t cc = 0;                                              // visible distance-1 guides, 8 bits per window
+            uint32_t k0 = 0, k1 = 0, k2 = 0;                              // entry of the (last) one
+            uint32_t d0 = 0, d1 = 0, d2 = 0;                              // its differing base (one bit of the rest)
+            if (vis && !(dbg & 1024)) {
+                const uint32_t b = sgc_core_home(sgc_hash(corev), cv.log2_p);
+                const uint32_t e_end = start[b + 1];
+                for (uint32_t i = start[b]; i < e_end; i++) {
+                    const uint64_t e = ent[i];
+                    if (((uint32_t)e & 0x3FFFFFFFu) != corev) continue;          // another core in the same bucket
+                    const uint32_t a = (uint32_t)e >> 30;
+                    if (!((vis >> a) & 1u)) continue;
+                    const uint32_t Ra = a == 0 ? R0 : (a == 1 ? R1 : R2), nr = a == 0 ? nr0 : (a == 1 ? nr1 : nr2);
+                    const uint32_t x = Ra ^ (uint32_t)(e >> 32);
+                    const uint32_t dm = ((x | (x >> 1)) & 0x55555555u) & ~nr;
+                    const uint32_t d = (uint32_t)__popc(dm) + (nr ? 1u : 0u);
+                    if (d == 0) { if (a == 0) ex0 = i; else if (a == 1) ex1 = i; else ex2 = i; }
+                    else if (d == 1) {
+                        cc += 1u << (8 * a);
+                        if (a == 0) { k0 = i; d0 = dm; } else if (a == 1) { k1 = i; d1 = dm; } else { k2 = i; d2 = dm; }
+                    }
+                }
+            }
+            // first level that holds, in the reference's order C, P, M; lvl: 0/1 C, 2/3 P, 4/5 M (odd = 1mm), 6 none
+            uint32_t res = SGC_NONE, lvl = 6, unk_above = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < 3; w++) {
+                const uint32_t a = w == 0 ? 1u : (w == 1 ? 2u : 0u);
+                const uint32_t ex = a == 0 ? ex0 : (a == 1 ? ex1 : ex2), c = (cc >> (8 * a)) & 255u;
+                const uint32_t k = a == 0 ? k0 : (a == 1 ? k1 : k2), dm = a == 0 ? d0 : (a == 1 ? d1 : d2);
+                const uint32_t nr = a == 0 ? nr0 : (a == 1 ? nr1 : nr2), Ra = a == 0 ? R0 : (a == 1 ? R1 : R2);
+                const uint32_t ll = a == 0 ? ll0 : (a == 1 ? ll1 : ll2);
+                if (lvl != 6) continue;
+                if (!((vis >> a) & 1u)) { unk_above |= unk & (1u << a); continue; }     // dead, or 'N' inside this core
+                if (ex != SGC_NONE) { res = ex; lvl = 2 * w; continue; }
+                if (c == 0) { if (!nr) unk_above |= 1u << a; continue; }                // clean: the substitution may sit in the core
+                if (c >= 2) continue;                                                   // two parents: no match
+                if (nr) { res = k; lvl = 2 * w + 1; continue; }                         // 'N': every candidate was visible
+                const uint32_t jr = (uint32_t)__builtin_ctz(dm) >> 1, j = jr < ll ? jr : jr + cl;
+                const uint32_t bit = 4 * j + ((Ra >> (2 * jr)) & 3u);
+                const ulonglong2 mk = (dbg & 2048) ? make_ulonglong2(0, 0) : amb[tgid[k]];
+                if (!(((bit < 64 ? mk.x : mk.y) >> (bit & 63)) & 1ull)) { res = k; lvl = 2 * w + 1; }
+            }
+            bool fwd_it = false;
+            if (valid) {
+                if (FINAL || unk_above == 0) {
+                    if (res != SGC_NONE) { atomicAdd(&cnt[res], 1u); local++; }
+                } else if (!(lvl & 1u)) {
+                    fwd_it = true;          // exact at P/M or nothing yet: pass B re-finds it and decides the levels above
+                } else {
+                    // single mismatch found at P or M while a higher single-mismatch level is undecided: settle those
+                    // with the global tables (rare)
+                    uint32_t g2 = SGC_NONE;
+#pragma unroll
+                    for (uint32_t w = 0; w < 2; w++) {
+                        const uint32_t a = w == 0 ? 1u : 2u;
+                        if (g2 != SGC_NONE || !(unk_above & (1u << a))) continue;
+                        const uint32_t sta = a == 1 ? st1 : st2;
+                        const uint64_t Wa = (span >> (2 * a)) & kmask;
+                        if (sta == SGC_STATE_CLEAN) g2 = table_find<true>(perm, Wa);
+                        else {
+                            uint32_t hit = SGC_NONE, nh = 0;
+                            for (uint64_t bb = 0; bb < 4; bb++) {
+                                const uint32_t x = table_find<true>(lib, Wa | (bb << (2 * (sta - 2u))));
+                                if (x != SGC_NONE) { hit = x; nh++; }
+                            }
+                            if (nh == 1) g2 = hit;
+                        }
+                    }
+                    if (g2 != SGC_NONE) atomicAdd(&counts[g2], 1u); else atomicAdd(&cnt[res], 1u);
+                    local++;
+                }
+            }
+            if (!FINAL) {
+                const uint64_t bal = __ballot(fwd_it);
+                if (bal) {
+                    const uint32_t lane = t & 63u;
+                    uint32_t b0 = 0;
+                    if (lane == (uint32_t)__builtin_ctzll(bal)) b0 = atomicAdd(&n_fwd, (uint32_t)__popcll(bal));
+                    b0 = __shfl(b0, __builtin_ctzll(bal), 64);
+                    if (fwd_it && !(dbg & 4096)) fwd[(uint64_t)wlo + b0 + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = rec;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (cur_p != 0xFFFFFFFFu && !(dbg & 8192))
+        for (uint32_t i = t; i < SGC_CORE_EMAX; i += KC_THREADS) {
+            const uint32_t v = cnt[i];
+            if (v) atomicAdd(&counts[tgid[i]], v);
+        }
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((t & 63) == 0 && local) atomicAdd(&wsum, (unsigned long long)local);
+    __syncthreads();
+    if (t == 0) {
+        if (wsum) atomicAdd(matched, wsum);
+        if (!FINAL) { ext_off[blockIdx.x] = wlo; ext_cnt[blockIdx.x] = n_fwd; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+void sgc_core_plan(uint64_t n, const sgc_core_view &a, const sgc_core_view &b, sgc_core_geometry *g) {
+    (void)a; (void)b;
+    g->w = CP_W;
+    g->grid_a = g->grid_b = KC_GRID;
+    g->recs_bytes = n * 8;                                        // each of the two record buffers
+    g->hist_bytes = (size_t)CP_MAXP * CP_W * 4;
+    g->small_bytes = g->hist_bytes + (size_t)2 * (CP_MAXP + 1) * 4 + (size_t)2 * KC_GRID * 4;
+}
+
+static void launch_partition(hipStream_t st, const uint64_t *in, const uint32_t *ext_off, const uint32_t *ext_cnt,
+                             uint32_t cnt_mask, uint32_t stride, uint32_t E, const sgc_core_view &cv, uint32_t L,
+                             uint32_t *hist, uint32_t *pstart, uint32_t *cstart, uint64_t *out) {
+    const uint32_t K = L + 2;
+    cp_args a;
+    a.in = in; a.ext_off = ext_off; a.ext_cnt = ext_cnt; a.cnt_mask = cnt_mask; a.stride = stride; a.E = E;
+    a.per = (E + CP_W - 1) / CP_W; a.cs2 = 2 * cv.cs; a.log2_p = cv.log2_p; a.sh = 2 * K;
+    a.dead_all = SGC_STATE_DEAD * (1 + K + K * K);
+    a.cmask = (1ull << (2 * cv.cl)) - 1ull;
+    hipLaunchKernelGGL(k_cp_hist, dim3(CP_W), dim3(CP_THREADS), 0, st, a, hist);
+    hipLaunchKernelGGL(k_cp_scan, dim3(1), dim3(CP_THREADS), 0, st, hist, 1u << cv.log2_p, pstart, cstart);
+    hipLaunchKernelGGL(k_cp_scatter, dim3(CP_W), dim3(CP_THREADS), 0, st, a, hist, pstart, out);
+}
+
+void sgc_launch_core(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm,
+                     const sgc_core_view &ca, const sgc_core_view &cb, const uint64_t *amb, const sgc_core_geometry &g,
+                     const uint64_t *pool, const uint32_t *desc, uint32_t n_blocks, uint32_t block_records,
+                     uint64_t *buf0, uint64_t *buf1, void *small, uint32_t *counts, unsigned long long *matched,
+                     uint32_t dbg) {
+    (void)g;
+    uint32_t *hist = (uint32_t *)small;
+    uint32_t *pstart = hist + (size_t)CP_MAXP * CP_W, *cstart = pstart + CP_MAXP + 1;
+    uint32_t *ext_off = cstart + CP_MAXP + 1, *ext_cnt = ext_off + KC_GRID;
+    const ulonglong2 *am = reinterpret_cast<const ulonglong2 *>(amb);
+    // pass A: the blocks of the slice-partitioned pool (K2 left the misses at the block fronts) -> buf0
+    launch_partition(st, pool, nullptr, desc, 0xFFFFu, block_records, n_blocks, ca, L, hist, pstart, cstart, buf0);
+    hipLaunchKernelGGL((k_core<false>), dim3(KC_GRID), dim3(KC_THREADS), 0, st, buf0, pstart, cstart, ca, am, L, lib, perm, buf1,
+                       ext_off, ext_cnt, counts, matched, dbg);
+    // pass B: what pass A forwarded (one run per pass-A workgroup in buf1) -> buf0
+    launch_partition(st, buf1, ext_off, ext_cnt, 0xFFFFFFFFu, 0, KC_GRID, cb, L, hist, pstart, cstart, buf0);
+    hipLaunchKernelGGL((k_core<true>), dim3(KC_GRID), dim3(KC_THREADS), 0, st, buf0, pstart, cstart, cb, am, L, lib, perm,
+                       (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, counts, matched, dbg);
+}
+
+// diagnostic (SGC_OCC_DBG=1 at sgc_set_library): resident workgroups per CU as the runtime computes them
+void sgc_core_print_occupancy() {
+    int a = -1, b = -1, c = -1, d = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_core<false>, KC_THREADS, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_core<true>, KC_THREADS, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, k_cp_scatter, CP_THREADS, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, k_cp_hist, CP_THREADS, 0);
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_core<false>));
+    fprintf(stderr, "occupancy (workgroups/CU): k_core<A> %d k_core<B> %d k_cp_scatter %d k_cp_hist %d; k_core<A> lds %zu regs %d\n", a, b, c, d,
+            fa.sharedSizeBytes, fa.numRegs);
+}

@@ -95,6 +95,33 @@ SGC_HD uint64_t sgc_hash2(uint64_t key) {
 SGC_HD uint32_t sgc_bloom_word(uint64_t h2, uint32_t log2_words) { return (uint32_t)(h2 >> (64 - log2_words)); }
 SGC_HD uint64_t sgc_bloom_mask(uint64_t h2) { return (1ull << (h2 & 63)) | (1ull << ((h2 >> 6) & 63)); }
 
+// Core index (sgc_core.hip): the guides seen through one *core* — span bases [cs, cs + cl), a stretch
+// that lies inside all three windows — at each of the three window alignments (0 = M, 1 = C, 2 = P; the
+// window starts at span base a, so the core sits at window positions [cs - a, cs - a + cl)).
+// 2^log2_p partitions by the hash of the core value; inside a partition the entries are bucketed (CSR) by
+// further hash bits: bucket b holds entries [starts[b], starts[b + 1]).  An entry is one u64:
+//   low 32 bits  = core value | alignment << 30
+//   high 32 bits = the REST of the guide: its bases outside the core, closed up (<= 2 * 14 bits)
+// and gids[] runs parallel to the entries.
+#define SGC_CORE_LOG2_S 12u                                  // buckets per partition (log2)
+#define SGC_CORE_EMAX 2048u                                  // entry capacity of a partition
+#define SGC_CORE_STARTS ((1u << SGC_CORE_LOG2_S) + 2u)       // u16 per partition in starts[] (NB + 1, padded)
+#define SGC_CORE_MAX_LOG2_P 8u
+struct sgc_core_view {
+    const uint64_t *ents;
+    const uint32_t *gids;
+    const uint16_t *starts;
+    uint32_t log2_p, cs, cl, pad_;
+};
+SGC_HD uint32_t sgc_core_part(uint64_t h, uint32_t log2_p) { return log2_p ? (uint32_t)(h >> (64 - log2_p)) : 0u; }
+SGC_HD uint32_t sgc_core_home(uint64_t h, uint32_t log2_p) {
+    return (uint32_t)(h >> (64 - log2_p - SGC_CORE_LOG2_S)) & ((1u << SGC_CORE_LOG2_S) - 1u);
+}
+// the bases of a window (2-bit packed, L bases) outside core positions [lowlen, lowlen + cl), closed up
+SGC_HD uint32_t sgc_core_rest(uint64_t window, uint32_t lowlen, uint32_t cl) {
+    return (uint32_t)((window & ((1ull << (2 * lowlen)) - 1ull)) | ((window >> (2 * (lowlen + cl))) << (2 * lowlen)));
+}
+
 // Builds one record from a read.  `emit(span_bits, status)` style is avoided to keep this usable in
 // kernels: returns span and status through references.
 SGC_HD void sgc_pack_one(const uint8_t *seq, uint64_t n, uint32_t L, int reverse, uint32_t o, int recursion,

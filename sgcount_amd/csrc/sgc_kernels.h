@@ -37,7 +37,7 @@ void sgc_launch_lookup_gids_v2(hipStream_t st, const uint64_t *recs, uint64_t n,
 
 // ---- partitioned count path (sgc_part.hip) ------------------------------------------------------
 struct sgc_part_geometry {
-    uint32_t k1_wgs, blocks_per_wg, n_blocks, partitions, n_segs;
+    uint32_t k1_wgs, blocks_per_wg, n_blocks, partitions, n_segs, block_records;
     uint64_t per_wg, pool_bytes, desc_bytes, gids_bytes;
 };
 bool sgc_part_supported(const sgc_table_view &lib, bool rec16);
@@ -54,6 +54,21 @@ void sgc_launch_part_generic(hipStream_t st, uint32_t L, const sgc_table_view &l
                              unsigned long long *matched);
 void sgc_launch_part_k4(hipStream_t st, uint32_t n_guides, const sgc_part_geometry &g, const uint32_t *gids,
                         const uint32_t *seg_cnt, uint32_t *counts, unsigned long long *matched);
+
+// ---- single-mismatch resolution in LDS (sgc_core.hip) -------------------------------------------
+struct sgc_core_geometry {
+    uint32_t w, grid_a, grid_b, pad_;
+    uint64_t recs_bytes, hist_bytes, small_bytes;
+};
+void sgc_core_plan(uint64_t n, const sgc_core_view &a, const sgc_core_view &b, sgc_core_geometry *g);
+// pool/desc: the slice-partitioned blocks after k_count_slices; buf0/buf1: recs_bytes each; small: small_bytes
+void sgc_launch_core(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm,
+                     const sgc_core_view &ca, const sgc_core_view &cb, const uint64_t *amb, const sgc_core_geometry &g,
+                     const uint64_t *pool, const uint32_t *desc, uint32_t n_blocks, uint32_t block_records,
+                     uint64_t *buf0, uint64_t *buf1, void *small, uint32_t *counts, unsigned long long *matched,
+                     uint32_t dbg);
+
+void sgc_core_print_occupancy();
 
 // ---- FASTQ ingest (sgc_fastq.hip) -----------------------------------------------------------------
 // tile_scratch: sgc_fastq_tiles(n) + 1 u32; after the call tile_scratch[tiles] = number of '\n' in the text

@@ -574,6 +574,7 @@ void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_
     g->n_segs = (g->n_blocks + K3_SEG - 1) / K3_SEG;
     g->gids_bytes = (uint64_t)g->n_segs * K3_SEG * PART_BLOCK * 4;
     g->partitions = P;
+    g->block_records = PART_BLOCK;
 }
 
 void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib,

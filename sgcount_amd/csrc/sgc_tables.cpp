@@ -127,7 +127,7 @@ uint32_t sgc_bloom_log2_words(uint64_t n_keys, uint32_t bits_per_key, uint32_t m
 }
 
 void sgc_build_permute_table(const std::vector<uint64_t> &keys, uint32_t L, const sgc_host_table &lib,
-                             sgc_host_table &out, std::vector<uint64_t> *child_keys) {
+                             sgc_host_table &out, std::vector<uint64_t> *child_keys, std::vector<uint64_t> *amb) {
     const uint32_t n = (uint32_t)keys.size();
     const uint32_t gb = lib.gid_bits;
     // all (child, parent) pairs: 3 ACGT substitutions per position (src/permutes.rs:78-107 minus the 'N' column).
@@ -164,6 +164,7 @@ void sgc_build_permute_table(const std::vector<uint64_t> &keys, uint32_t L, cons
     // per bucket run: keep children with exactly one parent that are not library members (src/permutes.rs:127-144:
     // a second sighting moves the child to `null`; a parent is in `null` from the start)
     if (child_keys) { child_keys->clear(); child_keys->reserve(total); }
+    if (amb) amb->assign((size_t)n * 2, 0);
     for (size_t i = 0; i < total;) {
         size_t j = i + 1;
         while (j < total && a[j].bucket == a[i].bucket) j++;
@@ -174,9 +175,59 @@ void sgc_build_permute_table(const std::vector<uint64_t> &keys, uint32_t L, cons
             if (v - u == 1 && table_find_host(lib, a[u].key) == SGC_NONE) {
                 table_insert(out, a[u].key, a[u].gid);
                 if (child_keys) child_keys->push_back(a[u].key);
+            } else if (amb) {
+                for (size_t q = u; q < v; q++) {
+                    const uint64_t x = a[q].key ^ keys[a[q].gid];            // one differing base
+                    const uint32_t j = (uint32_t)__builtin_ctzll(x) / 2, bit = 4 * j + (uint32_t)((a[q].key >> (2 * j)) & 3);
+                    (*amb)[(size_t)a[q].gid * 2 + (bit >> 6)] |= 1ull << (bit & 63);
+                }
             }
             u = v;
         }
         i = j;
     }
+}
+
+bool sgc_build_core_index(const std::vector<uint64_t> &keys, uint32_t L, uint32_t cs, uint32_t cl, sgc_host_core &out) {
+    const uint32_t n = (uint32_t)keys.size(), NB = 1u << SGC_CORE_LOG2_S;
+    if (cs < 2 || cl == 0 || cl > 14 || cs + cl > L || L > SGC_REC8_MAXL || L - cl > 16) return false;
+    const uint64_t cmask = (1ull << (2 * cl)) - 1ull;
+    std::vector<uint64_t> h((size_t)n * 3);
+    for (uint32_t g = 0; g < n; g++)
+        for (uint32_t a = 0; a < 3; a++)               // window position of span base cs at alignment a: cs - a
+            h[(size_t)g * 3 + a] = sgc_hash((keys[g] >> (2 * (cs - a))) & cmask);
+    uint32_t lp = 0;
+    std::vector<uint32_t> fill;
+    for (;; lp++) {
+        if (lp > SGC_CORE_MAX_LOG2_P) return false;
+        fill.assign(1u << lp, 0);
+        bool ok = true;
+        for (uint64_t x : h)
+            if (++fill[sgc_core_part(x, lp)] > SGC_CORE_EMAX) { ok = false; break; }
+        if (ok) break;
+    }
+    const size_t P = (size_t)1 << lp;
+    out.log2_p = lp; out.cs = cs; out.cl = cl;
+    out.ents.assign(P * SGC_CORE_EMAX, 0);
+    out.gids.assign(P * SGC_CORE_EMAX, SGC_NONE);
+    out.starts.assign(P * SGC_CORE_STARTS, 0);
+    // counting sort by (partition, bucket)
+    std::vector<uint32_t> cnt(P * (NB + 1), 0);
+    for (uint64_t x : h) cnt[(size_t)sgc_core_part(x, lp) * (NB + 1) + sgc_core_home(x, lp) + 1]++;
+    for (size_t p = 0; p < P; p++) {
+        uint32_t *c = &cnt[p * (NB + 1)];
+        for (uint32_t b = 0; b < NB; b++) c[b + 1] += c[b];
+        for (uint32_t b = 0; b <= NB; b++) out.starts[p * SGC_CORE_STARTS + b] = (uint16_t)c[b];
+    }
+    for (uint32_t g = 0; g < n; g++)
+        for (uint32_t a = 0; a < 3; a++) {
+            const uint64_t x = h[(size_t)g * 3 + a];
+            const size_t p = sgc_core_part(x, lp);
+            const uint32_t at = cnt[p * (NB + 1) + sgc_core_home(x, lp)]++;
+            const uint32_t lowlen = cs - a;
+            const uint64_t core = (keys[g] >> (2 * lowlen)) & cmask;
+            out.ents[p * SGC_CORE_EMAX + at] = core | ((uint64_t)a << 30) | ((uint64_t)sgc_core_rest(keys[g], lowlen, cl) << 32);
+            out.gids[p * SGC_CORE_EMAX + at] = g;
+        }
+    return true;
 }

@@ -29,8 +29,22 @@ int sgc_build_library_table(const uint8_t *seqs, uint32_t n, uint32_t L, uint32_
 // observe: child -> the UNIQUE guide at Hamming distance 1; children that are library members or have
 // two or more parents are dropped.  Only ACGT substitutions are stored; the 'N' children are resolved
 // in-kernel by probing the library (sgc_kernels.hip window_assign).
+// `amb` (optional): 2 u64 per guide, bit 4j + b set iff the child "guide with base b at position j" has two
+// or more parents (or is itself a library member), i.e. is NOT a key of the table.
 void sgc_build_permute_table(const std::vector<uint64_t> &keys, uint32_t L, const sgc_host_table &lib,
-                             sgc_host_table &out, std::vector<uint64_t> *child_keys = nullptr);
+                             sgc_host_table &out, std::vector<uint64_t> *child_keys = nullptr,
+                             std::vector<uint64_t> *amb = nullptr);
+
+// Core index over span bases [cs, cs + cl) (sgc_format.h sgc_core_view).  Returns false when the guides do
+// not spread over <= 2^SGC_CORE_MAX_LOG2_P partitions of at most SGC_CORE_EMAX entries (the caller then keeps the
+// probing resolver).
+struct sgc_host_core {
+    std::vector<uint64_t> ents;     // 2^log2_p x SGC_CORE_EMAX
+    std::vector<uint32_t> gids;     // parallel to ents
+    std::vector<uint16_t> starts;   // 2^log2_p x SGC_CORE_STARTS
+    uint32_t log2_p = 0, cs = 0, cl = 0;
+};
+bool sgc_build_core_index(const std::vector<uint64_t> &keys, uint32_t L, uint32_t cs, uint32_t cl, sgc_host_core &out);
 
 // Blocked Bloom filter over `keys` with 2^log2_words 64-bit words (sgc_format.h sgc_bloom_*).
 void sgc_build_bloom(const std::vector<uint64_t> &keys, uint32_t log2_words, std::vector<uint64_t> &out);

@@ -196,9 +196,12 @@ def _random_case(rng, L, n_guides, n_reads, o):
     return guides, reads
 
 
+@pytest.mark.parametrize("variant", [4, 3])
 @pytest.mark.parametrize("L,n_guides", [(20, 2000), (12, 300), (23, 500), (27, 400)])
 @pytest.mark.parametrize("reverse", [False, True])
-def test_random_vs_oracle(S, L, n_guides, reverse):
+def test_random_vs_oracle(S, L, n_guides, reverse, variant, monkeypatch):
+    """variant 4 = in-LDS core resolver (the default), 3 = probing resolver; both must give the oracle's table"""
+    monkeypatch.setenv("SGC_VARIANT", str(variant))
     rng = random.Random(1000 * L + n_guides + reverse)
     o = 9
     guides, reads = _random_case(rng, L, n_guides, 20000, o)
@@ -218,6 +221,65 @@ def test_random_vs_oracle(S, L, n_guides, reverse):
                 assert ctr.guide_counts().tolist() == want, (exact, recursion, pack)
                 assert (ctr.total_reads(), ctr.matched_reads()) == (tot, mat)
                 assert int(ctr.guide_counts().sum()) == mat
+
+
+def _dense_case(rng, L, o):
+    """Families built to stress the single-mismatch rules: siblings (guides one substitution apart: their
+    shared children are ambiguous), cousins (two apart: the child in between has two parents), and reads that
+    walk every substitution / 'N' at every position, at the three alignments, alone and combined."""
+    alpha = b"ACGT"
+    guides, seen = [], set()
+
+    def add(s):
+        s = bytes(s)
+        if s not in seen:
+            seen.add(s); guides.append(s)
+    for _ in range(12):
+        g = bytearray(rng.choice(alpha) for _ in range(L))
+        add(g)
+        for _ in range(3):                       # siblings and cousins
+            h = bytearray(g)
+            for _ in range(rng.choice([1, 2])):
+                h[rng.randrange(L)] = rng.choice(alpha)
+            add(h)
+        h = bytearray(g[1:] + bytes([rng.choice(alpha)]))      # the same guide shifted by one base
+        add(h)
+    while len(guides) < 200:
+        add(bytearray(rng.choice(alpha) for _ in range(L)))
+    reads = []
+    for g in guides[:70]:
+        for j in range(L):
+            for b in b"ACGTN":
+                w = bytearray(g); w[j] = b
+                for shift in (0, 1, -1):
+                    pre = bytes(rng.choice(alpha) for _ in range(o + shift))
+                    reads.append(pre + bytes(w) + bytes(rng.choice(alpha) for _ in range(3)))
+    for _ in range(4000):                        # two edits, 'N' + substitution, junk
+        w = bytearray(rng.choice(guides))
+        w[rng.randrange(L)] = rng.choice(b"ACGTN"); w[rng.randrange(L)] = rng.choice(b"ACGTN")
+        pre = bytes(rng.choice(b"ACGTN") for _ in range(o + rng.choice([0, 1, -1])))
+        reads.append(pre + bytes(w) + bytes(rng.choice(b"ACGTN") for _ in range(3)))
+    rng.shuffle(reads)
+    return guides, reads
+
+
+@pytest.mark.parametrize("L", [20, 23, 9, 6, 4])
+def test_dense_neighbourhoods_vs_oracle(S, L, monkeypatch):
+    """Every substitution and every 'N' of whole guide families, at all three alignments: the in-LDS core
+    resolver (variant 4), the probing resolver (variant 3) and the oracle agree read for read in aggregate."""
+    rng = random.Random(77 + L)
+    o = 5
+    guides, reads = _dense_case(rng, L, o)
+    lib_text, reads_text = _fasta(guides), _reads_fasta(reads)
+    for recursion in (True, False):
+        want, tot, mat = O.count_text(lib_text, reads_text, False, o, False, recursion)
+        for variant in (4, 3):
+            monkeypatch.setenv("SGC_VARIANT", str(variant))
+            lib = _lib(S, lib_text)
+            perm = S.Permuter.new(lib.keys())
+            ctr = S.Counter.new(S.parse_fastx(reads_text), lib, perm, S.Offset.Forward(o), L, recursion, pack="device")
+            assert ctr.guide_counts().tolist() == want, (variant, recursion)
+            assert (ctr.total_reads(), ctr.matched_reads()) == (tot, mat)
 
 
 def test_duplicate_ids_pool_counts(S):

@@ -199,12 +199,12 @@ def test_full_size_properties(env):
     c2, t2, m2 = wl.result()
     assert t2 == total and m2 == matched and np.array_equal(c2, counts)
     # every variant of the count path gives the same table
-    for v in (0, 1, 2):
+    for v in (0, 1, 2, 3):
         wl.dl.set_option("variant", v)
         wl.step()
         cv, tv, mv = wl.result()
         assert tv == total and mv == matched and np.array_equal(cv, counts), v
-    wl.dl.set_option("variant", 3)
+    wl.dl.set_option("variant", 4)
     # small internal chunks (several pool generations per push)
     wl.dl.set_option("max_chunk", 9_000_000)
     wl.step()
@@ -253,12 +253,14 @@ def test_extreme_skew(env):
     big = big[torch.randperm(big.numel(), device="cuda")]          # interleave the three kinds
     dl = library.device(True)
     dl.set_stream(torch.cuda.current_stream().cuda_stream)
-    smp = C.c_void_p()
-    ffi.check(dl.lib.sgc_sample_begin(dl.ctx, C.byref(smp), 0, 30, 1))
-    ffi.check(dl.lib.sgc_sample_push_packed(smp, big.data_ptr(), big.numel(), ffi.MEM_DEVICE))
-    out = np.zeros(100_000, dtype=np.uint64)
-    t, m = C.c_uint64(), C.c_uint64()
-    ffi.check(dl.lib.sgc_sample_finish(smp, out.ctypes.data, C.byref(t), C.byref(m)))
-    dl.lib.sgc_sample_free(smp)
-    assert t.value == sum(mult) and m.value == matched
-    assert np.array_equal(out, want)
+    for variant in (4, 3):
+        dl.set_option("variant", variant)
+        smp = C.c_void_p()
+        ffi.check(dl.lib.sgc_sample_begin(dl.ctx, C.byref(smp), 0, 30, 1))
+        ffi.check(dl.lib.sgc_sample_push_packed(smp, big.data_ptr(), big.numel(), ffi.MEM_DEVICE))
+        out = np.zeros(100_000, dtype=np.uint64)
+        t, m = C.c_uint64(), C.c_uint64()
+        ffi.check(dl.lib.sgc_sample_finish(smp, out.ctypes.data, C.byref(t), C.byref(m)))
+        dl.lib.sgc_sample_free(smp)
+        assert t.value == sum(mult) and m.value == matched, variant
+        assert np.array_equal(out, want), variant
