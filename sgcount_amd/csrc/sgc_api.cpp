@@ -171,7 +171,7 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
                 timed t(c, T_MISS);
                 sgc_launch_core(c->stream, c->L, c->v_lib, c->v_perm, c->v_core[0], c->v_core[1], c->d_amb, cg, pool, desc,
                                 g.n_blocks, g.block_records, (uint64_t *)c->d_cbuf, (uint64_t *)c->d_cbuf + chunk,
-                                c->d_csmall, s->d_c32, s->d_matched, c->dbg);
+                                (char *)c->d_desc + g.desc_tail_off, c->d_csmall, s->d_c32, s->d_matched, c->dbg);
                 HIP_TRY(hipGetLastError());
                 done += chunk;
                 s->since_fold += chunk;

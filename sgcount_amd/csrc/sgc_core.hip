@@ -26,8 +26,9 @@
 //   record goes on to pass B, which sees everything pass A could not, plus every exact level again.  The
 //   rare "1mm found at P/M in pass A, C-1mm undecided" case is closed on the spot with the global tables.
 //
-// Kernels: k_cp_hist / k_cp_scan / k_cp_scatter (two-pass counting partition of record *extents* into
-// contiguous per-partition ranges, LDS-staged so that the writes are runs) and k_core (the resolver).
+// Kernels: k_cp_count / k_cp_scatter (counting partition of record *extents* into contiguous per-partition
+// ranges, LDS-staged so that the writes are runs) and k_core (the resolver; pass A also counts what it forwards
+// by pass B's partitions, so pass B needs no counting kernel).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -37,11 +38,12 @@
 #include "sgc_kernels.h"
 
 #define CP_THREADS 1024u
-#define CP_W 256u                // workgroups of the partition kernels
-#define CP_TILE 8192u
+#define CP_W 512u                // workgroups of the partition kernels (two per CU)
+#define CP_TILE 4096u
 #define CP_SEG 1024u             // extents scanned per segment
 #define CP_MAXP (1u << SGC_CORE_MAX_LOG2_P)
 #define CP_DROP 0xFFFFu
+#define CP_CUR_STRIDE 32u         // one 128-byte line per partition cursor: atomics on one line serialise
 #define KC_THREADS 1024u
 #define KC_CHUNK 4096u           // records per unit of resolver work
 #define KC_GRID 512u
@@ -77,14 +79,53 @@ __device__ __forceinline__ uint32_t wg_scan_1024(uint32_t v, uint32_t *wsum /*[1
     return wsum[wave] + incl - v;
 }
 
-// last u in [0, ns) with off[u] <= d (entries with nothing in them share their offset with the next one)
+// last u in [0, ns) with off[u] <= d (entries with nothing in them share their offset with the next one);
+// branch-free with a fixed trip count
+template <uint32_t LOG2_MAX>
 __device__ __forceinline__ uint32_t find_extent(const uint32_t *off, uint32_t ns, uint32_t d) {
-    uint32_t lo = 0, hi = ns;            // invariant: off[lo] <= d, answer in [lo, hi)
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (off[mid] <= d) lo = mid; else hi = mid;
+    uint32_t lo = 0;                     // off[0] == 0 <= d
+#pragma unroll
+    for (uint32_t step = 1u << (LOG2_MAX - 1); step; step >>= 1) {
+        const uint32_t idx = lo + step;
+        const uint32_t v = off[idx < ns ? idx : 0];
+        lo = (idx < ns && v <= d) ? idx : lo;
     }
     return lo;
+}
+
+// map[j] = 1 + the extent (index inside the segment) that holds flat position r0 + j, for the CP_TILE
+// positions of a tile.  Thread t owns extent t (offset my_off, my_cnt records): it plants its number where
+// its extent starts (or at position 0 if the extent straddles r0); a running maximum over the positions —
+// four per thread, then waves, then the workgroup — spreads every number up to the next start.  Far fewer
+// instructions than a binary search per record.
+__device__ __forceinline__ void build_tile_map(uint16_t *map, uint32_t my_off, uint32_t my_cnt, uint32_t r0, uint32_t *wmax) {
+    static_assert(CP_TILE == 4 * CP_THREADS, "four map entries per thread");
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    uint64_t *m64 = reinterpret_cast<uint64_t *>(map);
+    m64[t] = 0;
+    __syncthreads();
+    if (my_cnt) {
+        if (my_off >= r0) { if (my_off - r0 < CP_TILE) map[my_off - r0] = (uint16_t)(t + 1); }
+        else if (my_off + my_cnt > r0) map[0] = (uint16_t)(t + 1);
+    }
+    __syncthreads();
+    const uint64_t v = m64[t];
+    uint32_t h0 = (uint32_t)(v & 0xFFFF), h1 = (uint32_t)((v >> 16) & 0xFFFF), h2 = (uint32_t)((v >> 32) & 0xFFFF), h3 = (uint32_t)(v >> 48);
+    h1 = h1 > h0 ? h1 : h0; h2 = h2 > h1 ? h2 : h1; h3 = h3 > h2 ? h3 : h2;
+    uint32_t incl = h3;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t x = __shfl_up(incl, off, 64);
+        if ((int)lane >= off && x > incl) incl = x;
+    }
+    if (lane == 63) wmax[wave] = incl;
+    uint32_t before = __shfl_up(incl, 1, 64);
+    if (lane == 0) before = 0;
+    __syncthreads();
+    for (uint32_t w = 0; w < wave; w++) { const uint32_t x = wmax[w]; before = x > before ? x : before; }
+    h0 = h0 > before ? h0 : before; h1 = h1 > before ? h1 : before; h2 = h2 > before ? h2 : before; h3 = h3 > before ? h3 : before;
+    m64[t] = (uint64_t)h0 | ((uint64_t)h1 << 16) | ((uint64_t)h2 << 32) | ((uint64_t)h3 << 48);
+    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------ partition
@@ -94,12 +135,14 @@ __device__ __forceinline__ uint32_t find_extent(const uint32_t *off, uint32_t ns
 struct cp_args {
     const uint64_t *in;
     const uint32_t *ext_off, *ext_cnt;
-    uint32_t cnt_mask, stride, E, per, cs2, log2_p, sh, dead_all;
+    uint32_t cnt_mask, stride, E, per, cs2, log2_p, sh, dead_all, dbg;
     uint64_t cmask;
 };
 
-__global__ void __launch_bounds__(CP_THREADS) k_cp_hist(cp_args a, uint32_t *__restrict__ hist) {
+// records per partition, added to tot[] (zeroed by the caller)
+__global__ void __launch_bounds__(CP_THREADS) k_cp_count(cp_args a, uint32_t *__restrict__ tot) {
     __shared__ uint32_t h[CP_MAXP], off_[CP_SEG], wsum[17];
+    __shared__ __attribute__((aligned(8))) uint16_t map[CP_TILE];
     const uint32_t t = threadIdx.x, P = 1u << a.log2_p;
     const uint32_t e0 = blockIdx.x * a.per, e1 = e0 + a.per < a.E ? e0 + a.per : a.E;
     if (t < CP_MAXP) h[t] = 0;
@@ -107,15 +150,17 @@ __global__ void __launch_bounds__(CP_THREADS) k_cp_hist(cp_args a, uint32_t *__r
         const uint32_t ns = e1 - s0 < CP_SEG ? e1 - s0 : CP_SEG;
         const uint32_t c = t < ns ? (a.ext_cnt[s0 + t] & a.cnt_mask) : 0;
         uint32_t T;
-        off_[t] = wg_scan_1024(c, wsum, &T);
+        const uint32_t my_off = wg_scan_1024(c, wsum, &T);
+        off_[t] = my_off;
         __syncthreads();
         for (uint32_t r0 = 0; r0 < T; r0 += CP_TILE) {
+            build_tile_map(map, my_off, c, r0, wsum);
             uint64_t rec[CP_TILE / CP_THREADS];
 #pragma unroll
             for (uint32_t k = 0; k < CP_TILE / CP_THREADS; k++) {       // all loads first: they overlap
                 const uint32_t d = r0 + k * CP_THREADS + t;
                 if (d < T) {
-                    const uint32_t u = find_extent(off_, ns, d);
+                    const uint32_t u = map[d - r0] - 1u;
                     rec[k] = a.in[(a.ext_off ? (uint64_t)a.ext_off[s0 + u] : (uint64_t)(s0 + u) * a.stride) + (d - off_[u])];
                 }
             }
@@ -131,76 +176,55 @@ __global__ void __launch_bounds__(CP_THREADS) k_cp_hist(cp_args a, uint32_t *__r
         __syncthreads();
     }
     __syncthreads();
-    if (t < P) hist[t * CP_W + blockIdx.x] = h[t];
+    if (t < P && h[t]) atomicAdd(&tot[t], h[t]);
 }
 
-// hist[P][CP_W] -> per-row exclusive prefix in place; pstart[p] = first record of partition p (pstart[P] =
-// total), cstart[p] = first KC_CHUNK-record chunk of partition p (cstart[P] = number of chunks)
-__global__ void __launch_bounds__(CP_THREADS) k_cp_scan(uint32_t *__restrict__ hist, uint32_t P, uint32_t *__restrict__ pstart,
-                                                        uint32_t *__restrict__ cstart) {
-    __shared__ uint32_t rowtot[CP_MAXP], wsum[17];
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    constexpr uint32_t RW = CP_MAXP / 16, CW = CP_W / 64;               // rows per wave, 64-wide pieces per row
-    uint32_t x[RW][CW];
-#pragma unroll
-    for (uint32_t r = 0; r < RW; r++)
-#pragma unroll
-        for (uint32_t k = 0; k < CW; k++) {
-            const uint32_t p = wave + 16 * r;
-            x[r][k] = p < P ? hist[p * CP_W + k * 64 + lane] : 0;
-        }
-#pragma unroll
-    for (uint32_t r = 0; r < RW; r++) {
-        const uint32_t p = wave + 16 * r;
-        uint32_t run = 0;
-#pragma unroll
-        for (uint32_t k = 0; k < CW; k++) {
-            uint32_t incl = x[r][k];
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t y = __shfl_up(incl, off, 64);
-                if ((int)lane >= off) incl += y;
-            }
-            if (p < P) hist[p * CP_W + k * 64 + lane] = run + incl - x[r][k];
-            run += __shfl(incl, 63, 64);
-        }
-        if (lane == 0 && p < CP_MAXP) rowtot[p] = run;
-    }
-    __syncthreads();
-    const uint32_t n = t < P ? rowtot[t] : 0;
+// tot[] (records per partition) -> ps[p] = first record of partition p (ps[P] = total) and cs[p] = first
+// KC_CHUNK-record chunk of partition p (cs[P] = number of chunks); ps/cs: LDS arrays of P + 1 entries
+__device__ __forceinline__ void starts_from_totals(const uint32_t *__restrict__ tot, uint32_t P, uint32_t *ps, uint32_t *cs,
+                                                   uint32_t *wsum) {
+    const uint32_t t = threadIdx.x;
+    const uint32_t n = t < P ? tot[t] : 0;
     uint32_t total, ctotal;
     const uint32_t pre = wg_scan_1024(n, wsum, &total);
     const uint32_t cpre = wg_scan_1024((n + KC_CHUNK - 1) / KC_CHUNK, wsum, &ctotal);
-    if (t < P) { pstart[t] = pre; cstart[t] = cpre; }
-    if (t == 0) { pstart[P] = total; cstart[P] = ctotal; }
+    if (t < P) { ps[t] = pre; if (cs) cs[t] = cpre; }
+    if (t == 0) { ps[P] = total; if (cs) cs[P] = ctotal; }
+    __syncthreads();
 }
 
-__global__ void __launch_bounds__(CP_THREADS) k_cp_scatter(cp_args a, const uint32_t *__restrict__ base,
-                                                           const uint32_t *__restrict__ pstart, uint64_t *__restrict__ out) {
+// Partition p's output range starts at ps[p] (from tot[]); a tile's run for p goes where an atomic on cursor[p]
+// (zeroed by the caller) says: the order of the runs inside a partition is whatever the race gives, which no
+// consumer depends on.
+__global__ void __launch_bounds__(CP_THREADS) k_cp_scatter(cp_args a, const uint32_t *__restrict__ tot,
+                                                           uint32_t *__restrict__ cursor, uint64_t *__restrict__ out) {
     __shared__ uint64_t stage[CP_TILE];
     __shared__ uint8_t stage_p[CP_TILE];
-    __shared__ uint32_t cnt[CP_MAXP], start[CP_MAXP], cur[CP_MAXP];
+    __shared__ uint32_t cnt[CP_MAXP], start[CP_MAXP], cur[CP_MAXP], ps[CP_MAXP + 1];
     __shared__ uint32_t off_[CP_SEG], wsum[17];
+    __shared__ __attribute__((aligned(8))) uint16_t map[CP_TILE];
     const uint32_t t = threadIdx.x, P = 1u << a.log2_p;
     const uint32_t e0 = blockIdx.x * a.per, e1 = e0 + a.per < a.E ? e0 + a.per : a.E;
-    if (t < P) cur[t] = pstart[t] + base[t * CP_W + blockIdx.x];
+    if (e0 >= e1) return;
+    starts_from_totals(tot, P, ps, nullptr, wsum);
     for (uint32_t s0 = e0; s0 < e1; s0 += CP_SEG) {
         const uint32_t ns = e1 - s0 < CP_SEG ? e1 - s0 : CP_SEG;
         const uint32_t c = t < ns ? (a.ext_cnt[s0 + t] & a.cnt_mask) : 0;
         uint32_t T;
-        off_[t] = wg_scan_1024(c, wsum, &T);
+        const uint32_t my_off = wg_scan_1024(c, wsum, &T);
+        off_[t] = my_off;
         __syncthreads();
         for (uint32_t r0 = 0; r0 < T; r0 += CP_TILE) {
             const uint32_t m = T - r0 < CP_TILE ? T - r0 : CP_TILE;
             if (t < CP_MAXP) cnt[t] = 0;
-            __syncthreads();
+            build_tile_map(map, my_off, c, r0, wsum);
             uint64_t rec[CP_TILE / CP_THREADS];
             uint32_t pr[CP_TILE / CP_THREADS];
 #pragma unroll
             for (uint32_t k = 0; k < CP_TILE / CP_THREADS; k++) {
                 const uint32_t j = k * CP_THREADS + t;
                 if (j < m) {
-                    const uint32_t d = r0 + j, u = find_extent(off_, ns, d);
+                    const uint32_t d = r0 + j, u = map[j] - 1u;
                     rec[k] = a.in[(a.ext_off ? (uint64_t)a.ext_off[s0 + u] : (uint64_t)(s0 + u) * a.stride) + (d - off_[u])];
                 }
             }
@@ -214,12 +238,12 @@ __global__ void __launch_bounds__(CP_THREADS) k_cp_scatter(cp_args a, const uint
                 }
             }
             __syncthreads();
-            uint32_t kept;
-            {
-                const uint32_t cc = t < P ? cnt[t] : 0;
-                const uint32_t st0 = wg_scan_1024(cc, wsum, &kept);
-                if (t < P) start[t] = st0;
-            }
+            // reserve the tile's runs: the atomics travel to the L2 and back while the scan and the staging go on
+            const uint32_t cc = t < P ? cnt[t] : 0;
+            uint32_t got = 0, kept;
+            if (cc && !(a.dbg & 16384)) got = atomicAdd(&cursor[t * CP_CUR_STRIDE], cc);
+            const uint32_t st0 = wg_scan_1024(cc, wsum, &kept);
+            if (t < P) start[t] = st0;
             __syncthreads();
 #pragma unroll
             for (uint32_t k = 0; k < CP_TILE / CP_THREADS; k++) {
@@ -229,13 +253,9 @@ __global__ void __launch_bounds__(CP_THREADS) k_cp_scatter(cp_args a, const uint
                     stage_p[at] = (uint8_t)(pr[k] >> 16);
                 }
             }
+            if (t < P) cur[t] = ps[t] + got - st0;          // stage position j of partition p goes to cur[p] + j
             __syncthreads();
-            for (uint32_t j = t; j < kept; j += CP_THREADS) {
-                const uint32_t p = stage_p[j];
-                out[(uint64_t)cur[p] + (j - start[p])] = stage[j];
-            }
-            __syncthreads();
-            if (t < P) cur[t] += cnt[t];
+            for (uint32_t j = t; j < kept && !(a.dbg & 32768); j += CP_THREADS) out[(uint64_t)(cur[stage_p[j]] + j)] = stage[j];
             __syncthreads();
         }
     }
@@ -250,20 +270,20 @@ __global__ void __launch_bounds__(CP_THREADS) k_cp_scatter(cp_args a, const uint
 // workgroup's run (ext_off/ext_cnt[workgroup] describe what was written).  FINAL = true (pass B): undecided = no.
 template <bool FINAL>
 __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(80))) k_core(
-    const uint64_t *__restrict__ in, const uint32_t *__restrict__ pstart, const uint32_t *__restrict__ cstart, sgc_core_view cv,
-    const ulonglong2 *__restrict__ amb, uint32_t L, sgc_table_view lib, sgc_table_view perm, uint64_t *__restrict__ fwd,
-    uint32_t *__restrict__ ext_off, uint32_t *__restrict__ ext_cnt, uint32_t *__restrict__ counts,
+    const uint64_t *__restrict__ in, const uint32_t *__restrict__ tot, sgc_core_view cv, const ulonglong2 *__restrict__ amb,
+    uint32_t L, sgc_table_view lib, sgc_table_view perm, uint64_t *__restrict__ fwd, uint32_t *__restrict__ ext_off,
+    uint32_t *__restrict__ ext_cnt, sgc_core_view nx, uint32_t *__restrict__ tot_next, uint32_t *__restrict__ counts,
     unsigned long long *__restrict__ matched, uint32_t dbg) {
     __shared__ uint64_t ent[SGC_CORE_EMAX];
     __shared__ uint32_t tgid[SGC_CORE_EMAX], cnt[SGC_CORE_EMAX];
     __shared__ uint16_t start[SGC_CORE_STARTS];
-    __shared__ uint32_t ps[CP_MAXP + 1], cs_[CP_MAXP + 1];
+    __shared__ uint32_t ps[CP_MAXP + 1], cs_[CP_MAXP + 1], hn[FINAL ? 1 : CP_MAXP], wtmp[17];
     __shared__ uint32_t n_fwd;
     __shared__ unsigned long long wsum;
     const uint32_t t = threadIdx.x, P = 1u << cv.log2_p;
-    if (t <= P) { ps[t] = pstart[t]; cs_[t] = cstart[t]; }
     if (t == 0) { n_fwd = 0; wsum = 0; }
-    __syncthreads();
+    if (!FINAL && t < CP_MAXP) hn[t] = 0;                  // what this workgroup forwards, by the next pass's partition
+    starts_from_totals(tot, P, ps, cs_, wtmp);
     const uint32_t C = cs_[P];
     const uint32_t c_lo = (uint32_t)((uint64_t)blockIdx.x * C / gridDim.x), c_hi = (uint32_t)((uint64_t)(blockIdx.x + 1) * C / gridDim.x);
     const uint32_t K = L + 2, sh = 2 * K, cs2 = 2 * cv.cs, cl = cv.cl;
@@ -273,8 +293,10 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     const uint32_t hs2 = 2 * (cv.cs + cl);                  // span bit where the bases above the core start
     const uint32_t hm = (uint32_t)((1ull << (2 * (L - cl))) - 1ull);   // a rest has L - cl bases
     uint32_t local = 0, cur_p = 0xFFFFFFFFu, wlo = 0;
+    unsigned long long ts_unp = 0, ts_scan = 0, ts_dec = 0, ts_out = 0, ts_begin = __builtin_amdgcn_s_memtime();
+    uint32_t n_it = 0;
     for (uint32_t ch = c_lo; ch < c_hi; ch++) {
-        const uint32_t p = find_extent(cs_, P, ch);
+        const uint32_t p = find_extent<SGC_CORE_MAX_LOG2_P>(cs_, P, ch);
         if (p != cur_p) {                                    // uniform over the workgroup
             __syncthreads();
             if (cur_p != 0xFFFFFFFFu && !(dbg & 8192))
@@ -303,6 +325,8 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
 #pragma unroll 1
         for (uint32_t i0 = lo; i0 < hi; i0 += KC_THREADS) {
             const bool valid = i0 + t < hi;
+            unsigned long long tsa = 0;
+            if (dbg & 512) { tsa = __builtin_amdgcn_s_memtime(); n_it++; }
             const uint64_t rec = r0;
             r0 = r1; r1 = r2; r2 = r3;
             const uint64_t span = rec & smask;
@@ -325,6 +349,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 if (st1 >= 2) { const uint32_t j = st1 - 2; if (j >= ll1 && j < ll1 + cl) { vis &= ~2u; unk |= 2u; } else nr1 = 1u << (2 * (j < ll1 ? j : j - cl)); }
                 if (st2 >= 2) { const uint32_t j = st2 - 2; if (j >= ll2 && j < ll2 + cl) { vis &= ~4u; unk |= 4u; } else nr2 = 1u << (2 * (j < ll2 ? j : j - cl)); }
             }
+            if (dbg & 512) { const unsigned long long x = __builtin_amdgcn_s_memtime(); ts_unp += x - tsa; tsa = x; }
             uint32_t ex0 = SGC_NONE, ex1 = SGC_NONE, ex2 = SGC_NONE;      // entry of the exact guide
             uint32_t cc = 0;                                              // visible distance-1 guides, 8 bits per window
             uint32_t k0 = 0, k1 = 0, k2 = 0;                              // entry of the (last) one
@@ -348,26 +373,37 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                     }
                 }
             }
-            // first level that holds, in the reference's order C, P, M; lvl: 0/1 C, 2/3 P, 4/5 M (odd = 1mm), 6 none
-            uint32_t res = SGC_NONE, lvl = 6, unk_above = 0;
-#pragma unroll
-            for (uint32_t w = 0; w < 3; w++) {
-                const uint32_t a = w == 0 ? 1u : (w == 1 ? 2u : 0u);
-                const uint32_t ex = a == 0 ? ex0 : (a == 1 ? ex1 : ex2), c = (cc >> (8 * a)) & 255u;
-                const uint32_t k = a == 0 ? k0 : (a == 1 ? k1 : k2), dm = a == 0 ? d0 : (a == 1 ? d1 : d2);
-                const uint32_t nr = a == 0 ? nr0 : (a == 1 ? nr1 : nr2), Ra = a == 0 ? R0 : (a == 1 ? R1 : R2);
-                const uint32_t ll = a == 0 ? ll0 : (a == 1 ? ll1 : ll2);
-                if (lvl != 6) continue;
-                if (!((vis >> a) & 1u)) { unk_above |= unk & (1u << a); continue; }     // dead, or 'N' inside this core
-                if (ex != SGC_NONE) { res = ex; lvl = 2 * w; continue; }
-                if (c == 0) { if (!nr) unk_above |= 1u << a; continue; }                // clean: the substitution may sit in the core
-                if (c >= 2) continue;                                                   // two parents: no match
-                if (nr) { res = k; lvl = 2 * w + 1; continue; }                         // 'N': every candidate was visible
+            if (dbg & 512) { const unsigned long long x = __builtin_amdgcn_s_memtime(); ts_scan += x - tsa; tsa = x; }
+            // Levels in the reference's order, as bits: 0 C-exact, 1 C-1mm, 2 P-exact, 3 P-1mm, 4 M-exact, 5 M-1mm.
+            // lm: the level holds on what this pass sees (1mm: exactly one visible parent; invisible windows
+            // found nothing).  um: the 1mm level cannot be decided here (a clean visible window with no
+            // candidate — the substitution may sit inside the core — or an 'N' inside the core).
+            const uint32_t cC = (cc >> 8) & 255u, cP = (cc >> 16) & 255u, cM = cc & 255u;
+            uint32_t lm = (ex1 != SGC_NONE ? 1u : 0u) | (cC == 1 ? 2u : 0u) | (ex2 != SGC_NONE ? 4u : 0u) | (cP == 1 ? 8u : 0u) |
+                          (ex0 != SGC_NONE ? 16u : 0u) | (cM == 1 ? 32u : 0u);
+            const uint32_t um = ((((vis >> 1) & 1u) && cC == 0 && !nr1) || (unk & 2u) ? 2u : 0u) |
+                                ((((vis >> 2) & 1u) && cP == 0 && !nr2) || (unk & 4u) ? 8u : 0u) |
+                                (((vis & 1u) && cM == 0 && !nr0) || (unk & 1u) ? 32u : 0u);
+            uint32_t lvl = 6, res = SGC_NONE;
+            while (lm) {
+                lvl = (uint32_t)__builtin_ctz(lm);
+                if (!(lvl & 1u)) { res = lvl == 0 ? ex1 : (lvl == 2 ? ex2 : ex0); break; }
+                // one visible parent: it is THE parent unless the child has another one inside the core (amb mask);
+                // an 'N' window saw all of its candidates
+                const uint32_t k = lvl == 1 ? k1 : (lvl == 3 ? k2 : k0), nr = lvl == 1 ? nr1 : (lvl == 3 ? nr2 : nr0);
+                res = k;
+                if (nr) break;
+                const uint32_t dm = lvl == 1 ? d1 : (lvl == 3 ? d2 : d0), Ra = lvl == 1 ? R1 : (lvl == 3 ? R2 : R0);
+                const uint32_t ll = lvl == 1 ? ll1 : (lvl == 3 ? ll2 : ll0);
                 const uint32_t jr = (uint32_t)__builtin_ctz(dm) >> 1, j = jr < ll ? jr : jr + cl;
                 const uint32_t bit = 4 * j + ((Ra >> (2 * jr)) & 3u);
                 const ulonglong2 mk = (dbg & 2048) ? make_ulonglong2(0, 0) : amb[tgid[k]];
-                if (!(((bit < 64 ? mk.x : mk.y) >> (bit & 63)) & 1ull)) { res = k; lvl = 2 * w + 1; }
+                if (!(((bit < 64 ? mk.x : mk.y) >> (bit & 63)) & 1ull)) break;
+                lm &= lm - 1u;                   // ambiguous child: this level fails, on to the next
+                lvl = 6; res = SGC_NONE;
             }
+            const uint32_t unk_above = um & ((1u << lvl) - 1u);
+            if (dbg & 512) { const unsigned long long x = __builtin_amdgcn_s_memtime(); ts_dec += x - tsa; tsa = x; }
             bool fwd_it = false;
             if (valid) {
                 if (FINAL || unk_above == 0) {
@@ -381,7 +417,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
 #pragma unroll
                     for (uint32_t w = 0; w < 2; w++) {
                         const uint32_t a = w == 0 ? 1u : 2u;
-                        if (g2 != SGC_NONE || !(unk_above & (1u << a))) continue;
+                        if (g2 != SGC_NONE || !(unk_above & (2u << (2 * w)))) continue;
                         const uint32_t sta = a == 1 ? st1 : st2;
                         const uint64_t Wa = (span >> (2 * a)) & kmask;
                         if (sta == SGC_STATE_CLEAN) g2 = table_find<true>(perm, Wa);
@@ -405,11 +441,18 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                     uint32_t b0 = 0;
                     if (lane == (uint32_t)__builtin_ctzll(bal)) b0 = atomicAdd(&n_fwd, (uint32_t)__popcll(bal));
                     b0 = __shfl(b0, __builtin_ctzll(bal), 64);
-                    if (fwd_it && !(dbg & 4096)) fwd[(uint64_t)wlo + b0 + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = rec;
+                    if (fwd_it && !(dbg & 4096)) {
+                        fwd[(uint64_t)wlo + b0 + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = rec;
+                        atomicAdd(&hn[sgc_core_part(sgc_hash((rec >> (2 * nx.cs)) & ((1ull << (2 * nx.cl)) - 1ull)), nx.log2_p)], 1u);
+                    }
                 }
             }
+            if (dbg & 512) { const unsigned long long x = __builtin_amdgcn_s_memtime(); ts_out += x - tsa; }
         }
     }
+    if ((dbg & 512) && (t & 63) == 0 && (blockIdx.x % 101) == 0 && (t >> 6) < 2)
+        printf("k_core<%d> wg %u wave %u: %u iters, load+unpack %llu scan %llu decide %llu out %llu total %llu ticks\n", (int)FINAL,
+               blockIdx.x, t >> 6, n_it, ts_unp, ts_scan, ts_dec, ts_out, (unsigned long long)(__builtin_amdgcn_s_memtime() - ts_begin));
     __syncthreads();
     if (cur_p != 0xFFFFFFFFu && !(dbg & 8192))
         for (uint32_t i = t; i < SGC_CORE_EMAX; i += KC_THREADS) {
@@ -423,6 +466,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
         if (wsum) atomicAdd(matched, wsum);
         if (!FINAL) { ext_off[blockIdx.x] = wlo; ext_cnt[blockIdx.x] = n_fwd; }
     }
+    if (!FINAL && t < (1u << nx.log2_p) && hn[t]) atomicAdd(&tot_next[t], hn[t]);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -431,42 +475,43 @@ void sgc_core_plan(uint64_t n, const sgc_core_view &a, const sgc_core_view &b, s
     g->w = CP_W;
     g->grid_a = g->grid_b = KC_GRID;
     g->recs_bytes = n * 8;                                        // each of the two record buffers
-    g->hist_bytes = (size_t)CP_MAXP * CP_W * 4;
-    g->small_bytes = g->hist_bytes + (size_t)2 * (CP_MAXP + 1) * 4 + (size_t)2 * KC_GRID * 4;
+    g->zero_bytes = (size_t)(2 + 2 * CP_CUR_STRIDE) * CP_MAXP * 4;   // totals A | totals B | cursors A | cursors B
+    g->small_bytes = (size_t)2 * KC_GRID * 4;                     // the extents pass A hands to pass B
 }
 
-static void launch_partition(hipStream_t st, const uint64_t *in, const uint32_t *ext_off, const uint32_t *ext_cnt,
-                             uint32_t cnt_mask, uint32_t stride, uint32_t E, const sgc_core_view &cv, uint32_t L,
-                             uint32_t *hist, uint32_t *pstart, uint32_t *cstart, uint64_t *out) {
+static cp_args partition_args(const uint64_t *in, const uint32_t *ext_off, const uint32_t *ext_cnt, uint32_t cnt_mask,
+                              uint32_t stride, uint32_t E, const sgc_core_view &cv, uint32_t L, uint32_t dbg) {
     const uint32_t K = L + 2;
     cp_args a;
     a.in = in; a.ext_off = ext_off; a.ext_cnt = ext_cnt; a.cnt_mask = cnt_mask; a.stride = stride; a.E = E;
     a.per = (E + CP_W - 1) / CP_W; a.cs2 = 2 * cv.cs; a.log2_p = cv.log2_p; a.sh = 2 * K;
     a.dead_all = SGC_STATE_DEAD * (1 + K + K * K);
     a.cmask = (1ull << (2 * cv.cl)) - 1ull;
-    hipLaunchKernelGGL(k_cp_hist, dim3(CP_W), dim3(CP_THREADS), 0, st, a, hist);
-    hipLaunchKernelGGL(k_cp_scan, dim3(1), dim3(CP_THREADS), 0, st, hist, 1u << cv.log2_p, pstart, cstart);
-    hipLaunchKernelGGL(k_cp_scatter, dim3(CP_W), dim3(CP_THREADS), 0, st, a, hist, pstart, out);
+    a.dbg = dbg;
+    return a;
 }
 
 void sgc_launch_core(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm,
                      const sgc_core_view &ca, const sgc_core_view &cb, const uint64_t *amb, const sgc_core_geometry &g,
                      const uint64_t *pool, const uint32_t *desc, uint32_t n_blocks, uint32_t block_records,
-                     uint64_t *buf0, uint64_t *buf1, void *small, uint32_t *counts, unsigned long long *matched,
+                     uint64_t *buf0, uint64_t *buf1, void *zeroed, void *small, uint32_t *counts, unsigned long long *matched,
                      uint32_t dbg) {
     (void)g;
-    uint32_t *hist = (uint32_t *)small;
-    uint32_t *pstart = hist + (size_t)CP_MAXP * CP_W, *cstart = pstart + CP_MAXP + 1;
-    uint32_t *ext_off = cstart + CP_MAXP + 1, *ext_cnt = ext_off + KC_GRID;
+    uint32_t *tot_a = (uint32_t *)zeroed, *tot_b = tot_a + CP_MAXP, *cur_a = tot_b + CP_MAXP, *cur_b = cur_a + CP_MAXP * CP_CUR_STRIDE;
+    static_assert((2 + 2 * CP_CUR_STRIDE) * CP_MAXP * 4 <= SGC_DESC_TAIL, "the zeroed tail of the descriptor buffer holds the counters");
+    uint32_t *ext_off = (uint32_t *)small, *ext_cnt = ext_off + KC_GRID;
     const ulonglong2 *am = reinterpret_cast<const ulonglong2 *>(amb);
     // pass A: the blocks of the slice-partitioned pool (K2 left the misses at the block fronts) -> buf0
-    launch_partition(st, pool, nullptr, desc, 0xFFFFu, block_records, n_blocks, ca, L, hist, pstart, cstart, buf0);
-    hipLaunchKernelGGL((k_core<false>), dim3(KC_GRID), dim3(KC_THREADS), 0, st, buf0, pstart, cstart, ca, am, L, lib, perm, buf1,
-                       ext_off, ext_cnt, counts, matched, dbg);
-    // pass B: what pass A forwarded (one run per pass-A workgroup in buf1) -> buf0
-    launch_partition(st, buf1, ext_off, ext_cnt, 0xFFFFFFFFu, 0, KC_GRID, cb, L, hist, pstart, cstart, buf0);
-    hipLaunchKernelGGL((k_core<true>), dim3(KC_GRID), dim3(KC_THREADS), 0, st, buf0, pstart, cstart, cb, am, L, lib, perm,
-                       (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, counts, matched, dbg);
+    const cp_args pa = partition_args(pool, nullptr, desc, 0xFFFFu, block_records, n_blocks, ca, L, dbg);
+    hipLaunchKernelGGL(k_cp_count, dim3(CP_W), dim3(CP_THREADS), 0, st, pa, tot_a);
+    hipLaunchKernelGGL(k_cp_scatter, dim3(CP_W), dim3(CP_THREADS), 0, st, pa, tot_a, cur_a, buf0);
+    hipLaunchKernelGGL((k_core<false>), dim3(KC_GRID), dim3(KC_THREADS), 0, st, buf0, tot_a, ca, am, L, lib, perm, buf1, ext_off,
+                       ext_cnt, cb, tot_b, counts, matched, dbg);
+    // pass B: what pass A forwarded (one run per pass-A workgroup in buf1; it also counted them by partition) -> buf0
+    const cp_args pb = partition_args(buf1, ext_off, ext_cnt, 0xFFFFFFFFu, 0, KC_GRID, cb, L, dbg);
+    hipLaunchKernelGGL(k_cp_scatter, dim3(CP_W), dim3(CP_THREADS), 0, st, pb, tot_b, cur_b, buf0);
+    hipLaunchKernelGGL((k_core<true>), dim3(KC_GRID), dim3(KC_THREADS), 0, st, buf0, tot_b, cb, am, L, lib, perm,
+                       (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, cb, (uint32_t *)nullptr, counts, matched, dbg);
 }
 
 // diagnostic (SGC_OCC_DBG=1 at sgc_set_library): resident workgroups per CU as the runtime computes them
@@ -475,9 +520,9 @@ void sgc_core_print_occupancy() {
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_core<false>, KC_THREADS, 0);
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_core<true>, KC_THREADS, 0);
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, k_cp_scatter, CP_THREADS, 0);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, k_cp_hist, CP_THREADS, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, k_cp_count, CP_THREADS, 0);
     hipFuncAttributes fa;
     (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_core<false>));
-    fprintf(stderr, "occupancy (workgroups/CU): k_core<A> %d k_core<B> %d k_cp_scatter %d k_cp_hist %d; k_core<A> lds %zu regs %d\n", a, b, c, d,
+    fprintf(stderr, "occupancy (workgroups/CU): k_core<A> %d k_core<B> %d k_cp_scatter %d k_cp_count %d; k_core<A> lds %zu regs %d\n", a, b, c, d,
             fa.sharedSizeBytes, fa.numRegs);
 }

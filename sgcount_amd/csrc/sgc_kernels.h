@@ -36,9 +36,11 @@ void sgc_launch_lookup_gids_v2(hipStream_t st, const uint64_t *recs, uint64_t n,
                                uint32_t *gids, unsigned long long *matched);
 
 // ---- partitioned count path (sgc_part.hip) ------------------------------------------------------
+#define SGC_DESC_TAIL 69632u
 struct sgc_part_geometry {
     uint32_t k1_wgs, blocks_per_wg, n_blocks, partitions, n_segs, block_records;
     uint64_t per_wg, pool_bytes, desc_bytes, gids_bytes;
+    uint64_t desc_tail_off;      // desc_bytes includes SGC_DESC_TAIL zeroed bytes at this offset (scratch counters of later stages)
 };
 bool sgc_part_supported(const sgc_table_view &lib, bool rec16);
 void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_part_geometry *g);
@@ -58,15 +60,16 @@ void sgc_launch_part_k4(hipStream_t st, uint32_t n_guides, const sgc_part_geomet
 // ---- single-mismatch resolution in LDS (sgc_core.hip) -------------------------------------------
 struct sgc_core_geometry {
     uint32_t w, grid_a, grid_b, pad_;
-    uint64_t recs_bytes, hist_bytes, small_bytes;
+    uint64_t recs_bytes, zero_bytes, small_bytes;
 };
 void sgc_core_plan(uint64_t n, const sgc_core_view &a, const sgc_core_view &b, sgc_core_geometry *g);
-// pool/desc: the slice-partitioned blocks after k_count_slices; buf0/buf1: recs_bytes each; small: small_bytes
+// pool/desc: the slice-partitioned blocks after k_count_slices; buf0/buf1: recs_bytes each; zeroed: zero_bytes of
+// zeros (stream-ordered before the call); small: small_bytes
 void sgc_launch_core(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm,
                      const sgc_core_view &ca, const sgc_core_view &cb, const uint64_t *amb, const sgc_core_geometry &g,
                      const uint64_t *pool, const uint32_t *desc, uint32_t n_blocks, uint32_t block_records,
-                     uint64_t *buf0, uint64_t *buf1, void *small, uint32_t *counts, unsigned long long *matched,
-                     uint32_t dbg);
+                     uint64_t *buf0, uint64_t *buf1, void *zeroed, void *small, uint32_t *counts,
+                     unsigned long long *matched, uint32_t dbg);
 
 void sgc_core_print_occupancy();
 

@@ -570,7 +570,8 @@ void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_
     g->blocks_per_wg = (uint32_t)(per / PART_BLOCK) + P + 1;           // full blocks + one open block per partition (incl. generic)
     g->n_blocks = wgs * g->blocks_per_wg;
     g->pool_bytes = (uint64_t)g->n_blocks * PART_BLOCK * 8;
-    g->desc_bytes = (uint64_t)g->n_blocks * 4;
+    g->desc_tail_off = ((uint64_t)g->n_blocks * 4 + 255) & ~255ull;
+    g->desc_bytes = g->desc_tail_off + SGC_DESC_TAIL;       // K1's memset zeroes the tail too
     g->n_segs = (g->n_blocks + K3_SEG - 1) / K3_SEG;
     g->gids_bytes = (uint64_t)g->n_segs * K3_SEG * PART_BLOCK * 4;
     g->partitions = P;
