@@ -54,7 +54,7 @@
 __device__ __forceinline__ uint32_t cp_part(uint64_t rec, uint32_t cs2, uint64_t cmask, uint32_t log2_p, uint32_t sh,
                                             uint32_t dead_all) {
     if ((uint32_t)(rec >> sh) == dead_all) return CP_DROP;
-    return sgc_core_part(sgc_hash((rec >> cs2) & cmask), log2_p);
+    return sgc_core_part(sgc_core_hash((uint32_t)((rec >> cs2) & cmask)), log2_p);
 }
 
 // exclusive scan of one value per thread over a 1024-thread workgroup; returns the prefix, *total = sum
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             uint32_t k0 = 0, k1 = 0, k2 = 0;                              // entry of the (last) one
             uint32_t d0 = 0, d1 = 0, d2 = 0;                              // its differing base (one bit of the rest)
             if (vis && !(dbg & 1024)) {
-                const uint32_t b = sgc_core_home(sgc_hash(corev), cv.log2_p);
+                const uint32_t b = sgc_core_home(sgc_core_hash(corev), cv.log2_p);
                 const uint32_t e_end = start[b + 1];
                 for (uint32_t i = start[b]; i < e_end; i++) {
                     const uint64_t e = ent[i];
@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                     b0 = __shfl(b0, __builtin_ctzll(bal), 64);
                     if (fwd_it && !(dbg & 4096)) {
                         fwd[(uint64_t)wlo + b0 + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = rec;
-                        atomicAdd(&hn[sgc_core_part(sgc_hash((rec >> (2 * nx.cs)) & ((1ull << (2 * nx.cl)) - 1ull)), nx.log2_p)], 1u);
+                        atomicAdd(&hn[sgc_core_part(sgc_core_hash((uint32_t)((rec >> (2 * nx.cs)) & ((1ull << (2 * nx.cl)) - 1ull))), nx.log2_p)], 1u);
                     }
                 }
             }

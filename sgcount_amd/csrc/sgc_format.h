@@ -113,9 +113,15 @@ struct sgc_core_view {
     const uint16_t *starts;
     uint32_t log2_p, cs, cl, pad_;
 };
-SGC_HD uint32_t sgc_core_part(uint64_t h, uint32_t log2_p) { return log2_p ? (uint32_t)(h >> (64 - log2_p)) : 0u; }
-SGC_HD uint32_t sgc_core_home(uint64_t h, uint32_t log2_p) {
-    return (uint32_t)(h >> (64 - log2_p - SGC_CORE_LOG2_S)) & ((1u << SGC_CORE_LOG2_S) - 1u);
+// 32-bit hash of a core value (<= 28 bits): its top bits pick the partition, the next ones the bucket
+SGC_HD uint32_t sgc_core_hash(uint32_t corev) {
+    uint32_t h = corev * 0x9E3779B1u;
+    h ^= h >> 16;
+    return h * 0x85EBCA6Bu;
+}
+SGC_HD uint32_t sgc_core_part(uint32_t h, uint32_t log2_p) { return log2_p ? h >> (32 - log2_p) : 0u; }
+SGC_HD uint32_t sgc_core_home(uint32_t h, uint32_t log2_p) {
+    return (h >> (32 - log2_p - SGC_CORE_LOG2_S)) & ((1u << SGC_CORE_LOG2_S) - 1u);
 }
 // the bases of a window (2-bit packed, L bases) outside core positions [lowlen, lowlen + cl), closed up
 SGC_HD uint32_t sgc_core_rest(uint64_t window, uint32_t lowlen, uint32_t cl) {

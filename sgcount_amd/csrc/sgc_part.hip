@@ -53,7 +53,8 @@ __device__ __forceinline__ uint32_t part_of(uint64_t rec, uint64_t kmask, uint32
 __global__ void __launch_bounds__(K1_THREADS) k_partition(const uint64_t *__restrict__ recs, uint64_t n, uint64_t per_wg,
                                                    uint32_t blocks_per_wg, uint32_t L, uint32_t log2_slots,
                                                    uint32_t log2_slice, uint64_t *__restrict__ pool,
-                                                   uint32_t *__restrict__ desc) {
+                                                   uint32_t *__restrict__ desc, uint32_t *__restrict__ tail,
+                                                   uint32_t tail_words) {
     __shared__ uint64_t stage[PART_TILE];
     __shared__ uint8_t stage_p[PART_TILE];               // partition of every staged record
     __shared__ uint32_t cnt[PART_ARR], start[PART_ARR], blk[PART_ARR], fill[PART_ARR];
@@ -151,6 +152,11 @@ __global__ void __launch_bounds__(K1_THREADS) k_partition(const uint64_t *__rest
         __syncthreads();
     }
     if (t <= P && blk[t] != 0xFFFFFFFFu) desc[blk[t]] = ((t + 1) << 16) | fill[t];
+    // the blocks this workgroup never handed out read as "no partition, no records"; workgroup 0 also clears the
+    // scratch counters behind the descriptors (no separate memset on the stream)
+    for (uint32_t i = next_free + t; i < blocks_per_wg; i += K1_THREADS) desc[block0 + i] = 0;
+    if (blockIdx.x == 0)
+        for (uint32_t i = t; i < tail_words; i += K1_THREADS) tail[i] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------ K2
@@ -571,7 +577,7 @@ void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_
     g->n_blocks = wgs * g->blocks_per_wg;
     g->pool_bytes = (uint64_t)g->n_blocks * PART_BLOCK * 8;
     g->desc_tail_off = ((uint64_t)g->n_blocks * 4 + 255) & ~255ull;
-    g->desc_bytes = g->desc_tail_off + SGC_DESC_TAIL;       // K1's memset zeroes the tail too
+    g->desc_bytes = g->desc_tail_off + SGC_DESC_TAIL;       // k_partition zeroes the tail too
     g->n_segs = (g->n_blocks + K3_SEG - 1) / K3_SEG;
     g->gids_bytes = (uint64_t)g->n_segs * K3_SEG * PART_BLOCK * 4;
     g->partitions = P;
@@ -580,9 +586,8 @@ void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_
 
 void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib,
                         const sgc_part_geometry &g, uint64_t *pool, uint32_t *desc) {
-    (void)hipMemsetAsync(desc, 0, g.desc_bytes, st);
     hipLaunchKernelGGL(k_partition, dim3(g.k1_wgs), dim3(K1_THREADS), 0, st, recs, n, g.per_wg, g.blocks_per_wg, L,
-                       lib.log2_slots, lib.log2_slice, pool, desc);
+                       lib.log2_slots, lib.log2_slice, pool, desc, (uint32_t *)((char *)desc + g.desc_tail_off), SGC_DESC_TAIL / 4);
 }
 
 void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_part_geometry &g,

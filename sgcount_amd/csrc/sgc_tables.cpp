@@ -192,17 +192,17 @@ bool sgc_build_core_index(const std::vector<uint64_t> &keys, uint32_t L, uint32_
     const uint32_t n = (uint32_t)keys.size(), NB = 1u << SGC_CORE_LOG2_S;
     if (cs < 2 || cl == 0 || cl > 14 || cs + cl > L || L > SGC_REC8_MAXL || L - cl > 16) return false;
     const uint64_t cmask = (1ull << (2 * cl)) - 1ull;
-    std::vector<uint64_t> h((size_t)n * 3);
+    std::vector<uint32_t> h((size_t)n * 3);
     for (uint32_t g = 0; g < n; g++)
         for (uint32_t a = 0; a < 3; a++)               // window position of span base cs at alignment a: cs - a
-            h[(size_t)g * 3 + a] = sgc_hash((keys[g] >> (2 * (cs - a))) & cmask);
+            h[(size_t)g * 3 + a] = sgc_core_hash((uint32_t)((keys[g] >> (2 * (cs - a))) & cmask));
     uint32_t lp = 0;
     std::vector<uint32_t> fill;
     for (;; lp++) {
         if (lp > SGC_CORE_MAX_LOG2_P) return false;
         fill.assign(1u << lp, 0);
         bool ok = true;
-        for (uint64_t x : h)
+        for (uint32_t x : h)
             if (++fill[sgc_core_part(x, lp)] > SGC_CORE_EMAX) { ok = false; break; }
         if (ok) break;
     }
@@ -213,7 +213,7 @@ bool sgc_build_core_index(const std::vector<uint64_t> &keys, uint32_t L, uint32_
     out.starts.assign(P * SGC_CORE_STARTS, 0);
     // counting sort by (partition, bucket)
     std::vector<uint32_t> cnt(P * (NB + 1), 0);
-    for (uint64_t x : h) cnt[(size_t)sgc_core_part(x, lp) * (NB + 1) + sgc_core_home(x, lp) + 1]++;
+    for (uint32_t x : h) cnt[(size_t)sgc_core_part(x, lp) * (NB + 1) + sgc_core_home(x, lp) + 1]++;
     for (size_t p = 0; p < P; p++) {
         uint32_t *c = &cnt[p * (NB + 1)];
         for (uint32_t b = 0; b < NB; b++) c[b + 1] += c[b];
@@ -221,7 +221,7 @@ bool sgc_build_core_index(const std::vector<uint64_t> &keys, uint32_t L, uint32_
     }
     for (uint32_t g = 0; g < n; g++)
         for (uint32_t a = 0; a < 3; a++) {
-            const uint64_t x = h[(size_t)g * 3 + a];
+            const uint32_t x = h[(size_t)g * 3 + a];
             const size_t p = sgc_core_part(x, lp);
             const uint32_t at = cnt[p * (NB + 1) + sgc_core_home(x, lp)]++;
             const uint32_t lowlen = cs - a;
