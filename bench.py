@@ -165,7 +165,8 @@ def main():
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                            "traffic_note": traffic_note,
-                           "kernel": "count pipeline (k_partition + k_count_slices + k_generic + k_resolve_miss + k_hist_segments)",
+                           "kernel": ("count pipeline (k_partition + k_count_slices + k_cp_count/k_cp_scatter + k_core, twice)" if not exact
+                                      else "count pipeline (k_partition + k_count_slices + k_generic + k_resolve_miss + k_hist_segments)"),
                            "algorithmic_bytes_per_read": bpr,
                            "kernel_ms_per_step": dom_ms / args.steps, "kernels": kernels}
         if world == 1 and args.cpu_seconds > 0:

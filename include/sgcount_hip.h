@@ -68,7 +68,9 @@ typedef struct {
     uint64_t lib_slots;        /* open-addressed slots of the library table */
     uint64_t perm_slots;       /* slots of the single-mismatch (permute) table, 0 if exact */
     uint64_t perm_entries;     /* unambiguous children stored (src/permutes.rs map.len(), ACGT children only) */
-    uint64_t table_bytes;      /* device bytes of both tables */
+    uint64_t table_bytes;      /* device bytes of the tables and indexes */
+    uint64_t core_partitions;  /* partitions of each core index of the in-LDS single-mismatch resolver;
+                                  0 = no core index (exact mode, or the guides do not spread): probing resolver */
 } sgc_lib_info;
 
 /* ---- context: device + library tables -------------------------------------------------------- */

@@ -442,6 +442,12 @@ int sgc_library_info(sgc_ctx *c, sgc_lib_info *out) {
     out->perm_entries = c->perm_entries;
     const uint64_t per = c->v_lib.gid_bits ? 8 : 12;
     out->table_bytes = (out->lib_slots + out->perm_slots) * per;
+    if (c->has_core) {
+        out->core_partitions = 1ull << c->v_core[0].log2_p;
+        for (int k = 0; k < 2; k++)
+            out->table_bytes += ((uint64_t)SGC_CORE_EMAX * 12 + SGC_CORE_STARTS * 2) << c->v_core[k].log2_p;
+        out->table_bytes += (uint64_t)c->n * 16;
+    }
     return SGC_OK;
 }
 

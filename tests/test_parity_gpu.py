@@ -282,6 +282,34 @@ def test_dense_neighbourhoods_vs_oracle(S, L, monkeypatch):
             assert (ctr.total_reads(), ctr.matched_reads()) == (tot, mat)
 
 
+def test_core_index_overflow_falls_back(S):
+    """3000 guides sharing their first 12 bases: one core value carries more entries than a core partition may
+    hold, so no core index is built and the probing resolver (variant 3) serves the library — same table."""
+    rng = random.Random(99)
+    L, o, head = 20, 5, b"ACGTTGCAACGT"
+    guides, seen = [], set()
+    while len(guides) < 3000:
+        g = head + bytes(rng.choice(b"ACGT") for _ in range(L - len(head)))
+        if g not in seen:
+            seen.add(g); guides.append(g)
+    reads = []
+    for _ in range(20000):
+        w = bytearray(rng.choice(guides))
+        if rng.random() < 0.5:
+            w[rng.randrange(L)] = rng.choice(b"ACGTN")
+        pre = bytes(rng.choice(b"ACGT") for _ in range(o + rng.choice([0, 0, 1, -1])))
+        reads.append(pre + bytes(w) + b"GATTACA")
+    lib_text, reads_text = _fasta(guides), _reads_fasta(reads)
+    want, tot, mat = O.count_text(lib_text, reads_text, False, o, False, True)
+    lib = _lib(S, lib_text)
+    assert lib.device(True).info().core_partitions == 0
+    ctr = S.Counter.new(S.parse_fastx(reads_text), lib, S.Permuter.new(lib.keys()), S.Offset.Forward(o), L, True, pack="device")
+    assert ctr.guide_counts().tolist() == want and (ctr.total_reads(), ctr.matched_reads()) == (tot, mat)
+    # an ordinary library of the same size gets its core index
+    other = _lib(S, _fasta(_random_case(random.Random(3), L, 3000, 1, o)[0]))
+    assert other.device(True).info().core_partitions >= 1
+
+
 def test_duplicate_ids_pool_counts(S):
     """counter.rs:232-235 folds by id: two guides sharing an id report the pooled count on both rows"""
     lib_text = b">same\nACGTAC\n>same\nTTGCAA\n>other\nCCCCCC\n"

@@ -16,18 +16,20 @@ import json
 import os
 import sys
 
-PIPE = ("k_partition", "k_count_slices", "k_generic", "k_resolve_miss", "k_hist_segments", "k_export")
+PIPE = ("k_partition", "k_count_slices", "k_cp_count", "k_cp_scatter", "k_core", "k_generic", "k_resolve_miss", "k_hist_segments",
+        "k_export")
 
 
 def per_kernel(d, counter):
-    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
         acc[name].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}          # mean per dispatch (= per step)
+    steps = len(acc["k_partition"])                               # one k_partition launch per step
+    return {k: sum(v) / steps for k, v in acc.items()}            # per step (a kernel may run twice in a step)
 
 
 def main():
