@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     starts_from_totals(tot, P, ps, cs_, wtmp);
     const uint32_t C = cs_[P];
     const uint32_t c_lo = (uint32_t)((uint64_t)blockIdx.x * C / gridDim.x), c_hi = (uint32_t)((uint64_t)(blockIdx.x + 1) * C / gridDim.x);
-    const uint32_t K = L + 2, sh = 2 * K, cs2 = 2 * cv.cs, cl = cv.cl;
+    const uint32_t K = L + 2, sh = 2 * K, cs2 = 2 * cv.cs, cl = cv.cl, kdiv = (1u << 20) / K + 1u;
     const uint64_t smask = (1ull << sh) - 1ull, kmask = sgc_key_mask(L), cmask = (1ull << (2 * cl)) - 1ull;
     // window a (0 = M, 1 = C, 2 = P) starts at span base a: its core sits at window positions [ll_a, ll_a + cl)
     const uint32_t ll0 = cv.cs, ll1 = cv.cs - 1, ll2 = cv.cs - 2;
@@ -341,7 +341,10 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             // here ('N' inside the core); nr_a: the 'N' position as a bit of the rest (0 = clean)
             uint32_t vis = valid ? 7u : 0u, unk = 0, nr0 = 0, nr1 = 0, nr2 = 0, st0 = 0, st1 = 0, st2 = 0;
             if (status) {
-                st1 = status % K; st2 = (status / K) % K; st0 = status / (K * K);
+                // status = sC + K (sP + K sM); n / K as a multiply-shift (exact for n < K^3 <= 2^14, K <= 25: checked
+                // for every such n by tests/test_abi_cpu.py::test_status_division_magic)
+                const uint32_t q1 = (status * kdiv) >> 20;
+                st0 = (q1 * kdiv) >> 20; st1 = status - q1 * K; st2 = q1 - st0 * K;
                 if (st0 == SGC_STATE_DEAD) vis &= ~1u;
                 if (st1 == SGC_STATE_DEAD) vis &= ~2u;
                 if (st2 == SGC_STATE_DEAD) vis &= ~4u;

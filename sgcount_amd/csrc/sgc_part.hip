@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     __shared__ ulonglong2 tab[S / 2];                        // the slice, bucket by bucket
     __shared__ uint32_t cnt[S];
     __shared__ uint32_t list[K2_LIST];                       // block id << 11 | (fill - 1)
-    __shared__ uint32_t n_list, over_at, miss_cnt[2][K2_U];
+    __shared__ uint32_t n_list, over_at, miss_cnt[2][K2_U], scratch[128];
     const uint32_t t = threadIdx.x, p = blockIdx.x / G, g = blockIdx.x % G;
     const uint32_t slice = lib.log2_slice < (uint32_t)LOG2_SLICE ? (1u << lib.log2_slice) : S;   // small libraries
     const uint32_t bmask = slice / 2 - 1u, gid_bits = lib.gid_bits;
@@ -289,10 +289,12 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                     hit = wv.x == key || wv.y == key;
                     cont = !hit && wv.y != SGC_EMPTY;
                 }
-                if (valid) {
-                    if (hit) atomicAdd(&cnt[2 * b + (wv.x == key ? 0u : 1u)], 1u);
-                    else pool[(uint64_t)(ce[u] >> 11) * PART_BLOCK + atomicAdd(&miss_cnt[par][u], 1u)] = cur[q];
-                }
+                // Predicated, not branched (every exec-mask change costs scalar instructions, and K2 is bound by
+                // its scalar unit): lanes with nothing to add hit a scratch word of their own.
+                const bool hv = valid && hit, mv = valid && !hit;
+                atomicAdd(hv ? &cnt[2 * b + (wv.x == key ? 0u : 1u)] : &scratch[t & 63u], 1u);
+                const uint32_t pos = atomicAdd(mv ? &miss_cnt[par][u] : &scratch[64u + (t & 63u)], 1u);
+                if (mv) pool[(uint64_t)(ce[u] >> 11) * PART_BLOCK + pos] = cur[q];
             }
 #pragma unroll
             for (uint32_t q = 0; q < Q; q++) cur[q] = nxt[q];

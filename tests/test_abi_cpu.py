@@ -86,3 +86,11 @@ def test_k2_group_hash_is_balanced():
         h = (((ids * np.uint64(0x9E3779B1)) & np.uint64(0xFFFFFFFF)) >> np.uint64(16)) & np.uint64(G - 1)
         counts = np.bincount(h.astype(np.int64), minlength=G)
         assert counts.max() < 1.1 * counts.mean() + 8 and counts.min() > 0.9 * counts.mean() - 8, (G, counts.min(), counts.max())
+
+
+def test_status_division_magic():
+    """k_core decodes status = sC + K (sP + K sM) with n // K == (n * (2^20 // K + 1)) >> 20; exact for every
+    status a record can carry (n < K^3, K = L + 2 <= 25 for one-u64 records)."""
+    for K in range(3, 26):
+        m = (1 << 20) // K + 1
+        assert all(((n * m) >> 20) == n // K for n in range(K ** 3)), K
