@@ -6,9 +6,33 @@ src/count.rs:117-136) and collects the Counters in input order; here one process
 `rank, rank + world, ...` and the `[n_samples x (n_guides + 2)]` matrix (counts | total_reads | matched_reads per
 sample) is assembled with one all-reduce of a zero-padded matrix — each entry has exactly one non-zero
 contributor, so the sum is exact in integers.
+
+A single large sample can instead be split across the ranks (`shard_reads` + `reduce_sample_row`): reads are
+independent and counts additive, so every rank counts a slice against the replicated tables and the partial rows
+are summed with one reduce.
 """
 import torch
 import torch.distributed as dist
+
+
+def shard_reads(n_reads: int, world: int, rank: int):
+    """Within-sample sharding (counts are additive over reads): the contiguous slice [first, first + count) of a
+    sample's reads that `rank` counts; slices differ by at most one read."""
+    base, extra = divmod(n_reads, world)
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+def reduce_sample_row(row: torch.Tensor, dst: int = None, group=None):
+    """Sum the partial rows (counts | total_reads | matched_reads) of ONE sample whose reads were dealt to all
+    ranks: one all-reduce (dst=None) or reduce-to-dst of n_guides + 2 int64 — 0.8 MB at 100k guides, a single
+    hop on the xGMI mesh.  In place; returns row."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dst is None:
+            dist.all_reduce(row, op=dist.ReduceOp.SUM, group=group)
+        else:
+            dist.reduce(row, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return row
 
 
 def assign_samples(n_samples: int, world: int, rank: int):

@@ -71,3 +71,46 @@ def test_assign_samples_round_robin():
     assert assign_samples(1, 8, 3) == [] and assign_samples(8, 8, 7) == [7]
     seen = sorted(i for r in range(4) for i in assign_samples(10, 4, r))
     assert seen == list(range(10))
+
+
+def _worker_within(rank, world, port, n_reads, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import _oracle as O
+    from sgcount_amd import synth
+    from sgcount_amd.distributed import reduce_sample_row, shard_reads
+    lib = synth.library(300, 20)
+    first, count = shard_reads(n_reads, world, rank)
+    counts, tot, mat = O.count_text(synth.library_fasta(lib), synth.fastq_host(lib, first, count), False, 30, False, True) \
+        if count else ([0] * 300, 0, 0)
+    row = reduce_sample_row(torch.tensor(counts + [tot, mat], dtype=torch.int64))
+    np.save(os.path.join(out_dir, "within%d.npy" % rank), row.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_reads", [3001, 1])
+def test_two_rank_within_sample(tmp_path, n_reads):
+    """One sample, reads dealt to two ranks, partial rows summed: equals counting the whole sample at once."""
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import _oracle as O
+    from sgcount_amd import synth
+    world, port = 2, _free_port()
+    mp.spawn(_worker_within, args=(world, port, n_reads, str(tmp_path)), nprocs=world, join=True)
+    lib = synth.library(300, 20)
+    counts, tot, mat = O.count_text(synth.library_fasta(lib), synth.fastq_host(lib, 0, n_reads), False, 30, False, True)
+    for r in range(world):
+        assert np.load(os.path.join(str(tmp_path), "within%d.npy" % r)).tolist() == counts + [tot, mat]
+
+
+def test_shard_reads_covers_everything():
+    from sgcount_amd.distributed import shard_reads
+    for n, w in ((10, 4), (3, 8), (0, 2), (100_000_000, 8)):
+        parts = [shard_reads(n, w, r) for r in range(w)]
+        assert parts[0][0] == 0 and sum(c for _, c in parts) == n
+        assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+        assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
