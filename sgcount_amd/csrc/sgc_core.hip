@@ -57,42 +57,6 @@ __device__ __forceinline__ uint32_t cp_part(uint64_t rec, uint32_t cs2, uint64_t
     return sgc_core_part(sgc_core_hash((uint32_t)((rec >> cs2) & cmask)), log2_p);
 }
 
-// exclusive scan of one value per thread over a 1024-thread workgroup; returns the prefix, *total = sum
-__device__ __forceinline__ uint32_t wg_scan_1024(uint32_t v, uint32_t *wsum /*[17] in LDS*/, uint32_t *total) {
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    uint32_t incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t x = __shfl_up(incl, off, 64);
-        if ((int)lane >= off) incl += x;
-    }
-    __syncthreads();                       // wsum may still be read from a previous call
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    if (t == 0) {
-        uint32_t run = 0;
-        for (uint32_t w = 0; w < 16; w++) { const uint32_t x = wsum[w]; wsum[w] = run; run += x; }
-        wsum[16] = run;
-    }
-    __syncthreads();
-    *total = wsum[16];
-    return wsum[wave] + incl - v;
-}
-
-// last u in [0, ns) with off[u] <= d (entries with nothing in them share their offset with the next one);
-// branch-free with a fixed trip count
-template <uint32_t LOG2_MAX>
-__device__ __forceinline__ uint32_t find_extent(const uint32_t *off, uint32_t ns, uint32_t d) {
-    uint32_t lo = 0;                     // off[0] == 0 <= d
-#pragma unroll
-    for (uint32_t step = 1u << (LOG2_MAX - 1); step; step >>= 1) {
-        const uint32_t idx = lo + step;
-        const uint32_t v = off[idx < ns ? idx : 0];
-        lo = (idx < ns && v <= d) ? idx : lo;
-    }
-    return lo;
-}
-
 // map[j] = 1 + the extent (index inside the segment) that holds flat position r0 + j, for the CP_TILE
 // positions of a tile.  Thread t owns extent t (offset my_off, my_cnt records): it plants its number where
 // its extent starts (or at position 0 if the extent straddles r0); a running maximum over the positions —

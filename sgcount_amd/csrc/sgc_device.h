@@ -105,3 +105,43 @@ __device__ __forceinline__ void load_record(const uint64_t *recs, uint64_t i, ui
         status = r >> sh;
     }
 }
+
+// ------------------------------------------------------------------------------------------------
+// workgroup helpers shared by the partitioned kernels
+// ------------------------------------------------------------------------------------------------
+// exclusive scan of one value per thread over a 1024-thread workgroup; returns the prefix, *total = sum
+__device__ __forceinline__ uint32_t wg_scan_1024(uint32_t v, uint32_t *wsum /*[17] in LDS*/, uint32_t *total) {
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t x = __shfl_up(incl, off, 64);
+        if ((int)lane >= off) incl += x;
+    }
+    __syncthreads();                       // wsum may still be read from a previous call
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (uint32_t w = 0; w < 16; w++) { const uint32_t x = wsum[w]; wsum[w] = run; run += x; }
+        wsum[16] = run;
+    }
+    __syncthreads();
+    *total = wsum[16];
+    return wsum[wave] + incl - v;
+}
+
+// last u in [0, ns) with off[u] <= d (entries with nothing in them share their offset with the next one);
+// branch-free with a fixed trip count
+template <uint32_t LOG2_MAX>
+__device__ __forceinline__ uint32_t find_extent(const uint32_t *off, uint32_t ns, uint32_t d) {
+    uint32_t lo = 0;                     // off[0] == 0 <= d
+#pragma unroll
+    for (uint32_t step = 1u << (LOG2_MAX - 1); step; step >>= 1) {
+        const uint32_t idx = lo + step;
+        const uint32_t v = off[idx < ns ? idx : 0];
+        lo = (idx < ns && v <= d) ? idx : lo;
+    }
+    return lo;
+}
+

@@ -40,6 +40,7 @@ void sgc_launch_lookup_gids_v2(hipStream_t st, const uint64_t *recs, uint64_t n,
 struct sgc_part_geometry {
     uint32_t k1_wgs, blocks_per_wg, n_blocks, partitions, n_segs, block_records;
     uint64_t per_wg, pool_bytes, desc_bytes, gids_bytes;
+    uint64_t wcnt_off, wlist_off; // per-(K1 workgroup, partition) block counts and lists, behind the descriptors
     uint64_t desc_tail_off;      // desc_bytes includes SGC_DESC_TAIL zeroed bytes at this offset (scratch counters of later stages)
 };
 bool sgc_part_supported(const sgc_table_view &lib, bool rec16);

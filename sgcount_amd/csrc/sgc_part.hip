@@ -54,11 +54,12 @@ __global__ void __launch_bounds__(K1_THREADS) k_partition(const uint64_t *__rest
                                                    uint32_t blocks_per_wg, uint32_t L, uint32_t log2_slots,
                                                    uint32_t log2_slice, uint64_t *__restrict__ pool,
                                                    uint32_t *__restrict__ desc, uint32_t *__restrict__ tail,
-                                                   uint32_t tail_words) {
+                                                   uint32_t tail_words, uint32_t *__restrict__ wcnt,
+                                                   uint32_t *__restrict__ wlist) {
     __shared__ uint64_t stage[PART_TILE];
     __shared__ uint8_t stage_p[PART_TILE];               // partition of every staged record
     __shared__ uint32_t cnt[PART_ARR], start[PART_ARR], blk[PART_ARR], fill[PART_ARR];
-    __shared__ uint32_t dst_a[PART_ARR], dst_b[PART_ARR], split[PART_ARR];
+    __shared__ uint32_t dst_a[PART_ARR], dst_b[PART_ARR], split[PART_ARR], nblk[PART_ARR];
     __shared__ uint32_t next_free;
     const uint32_t P = 1u << (log2_slots - log2_slice), t = threadIdx.x;     // library slices; partition P = generic
     const uint32_t sh = 2 * (L + 2);
@@ -66,7 +67,7 @@ __global__ void __launch_bounds__(K1_THREADS) k_partition(const uint64_t *__rest
     const uint64_t lo = (uint64_t)blockIdx.x * per_wg;
     const uint64_t hi = lo + per_wg < n ? lo + per_wg : n;
     const uint32_t block0 = blockIdx.x * blocks_per_wg;
-    if (t < PART_ARR) { blk[t] = 0xFFFFFFFFu; fill[t] = PART_BLOCK; }
+    if (t < PART_ARR) { blk[t] = 0xFFFFFFFFu; fill[t] = PART_BLOCK; nblk[t] = 0; }
     if (t == 0) next_free = 0;
     __syncthreads();
     for (uint64_t base = lo; base < hi; base += PART_TILE) {
@@ -124,6 +125,11 @@ __global__ void __launch_bounds__(K1_THREADS) k_partition(const uint64_t *__rest
                         if (blk[q] != 0xFFFFFFFFu) desc[blk[q]] = ((q + 1) << 16) | PART_BLOCK;    // close, full
                         const uint32_t x = block0 + atomicAdd(&next_free, nb);
                         for (uint32_t i = 0; i + 1 < nb; i++) desc[x + i] = ((q + 1) << 16) | PART_BLOCK;
+                        // the partition's blocks from this workgroup, in order: k_count_slices walks these lists
+                        // instead of scanning every descriptor
+                        uint32_t *wl = wlist + ((size_t)blockIdx.x * PART_ARR + q) * blocks_per_wg + nblk[q];
+                        for (uint32_t i = 0; i < nb; i++) wl[i] = x + i;
+                        nblk[q] += nb;
                         blk[q] = x + nb - 1;
                         dst_b[q] = x * PART_BLOCK;
                         fill[q] = rem - (nb - 1) * PART_BLOCK;
@@ -155,6 +161,7 @@ __global__ void __launch_bounds__(K1_THREADS) k_partition(const uint64_t *__rest
     // the blocks this workgroup never handed out read as "no partition, no records"; workgroup 0 also clears the
     // scratch counters behind the descriptors (no separate memset on the stream)
     for (uint32_t i = next_free + t; i < blocks_per_wg; i += K1_THREADS) desc[block0 + i] = 0;
+    if (t < PART_ARR) wcnt[blockIdx.x * PART_ARR + t] = nblk[t];
     if (blockIdx.x == 0)
         for (uint32_t i = t; i < tail_words; i += K1_THREADS) tail[i] = 0;
 }
@@ -169,7 +176,8 @@ __global__ void __launch_bounds__(K1_THREADS) k_partition(const uint64_t *__rest
 #define K2_SCAN 16u              // descriptors examined per lane per scan chunk
 template <int LOG2_SLICE>
 __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(80))) k_count_slices(uint64_t *__restrict__ pool, uint32_t *__restrict__ desc,
-                                                             uint32_t n_blocks, uint32_t G, uint32_t L,
+                                                             const uint32_t *__restrict__ wcnt, const uint32_t *__restrict__ wlist,
+                                                             uint32_t k1_wgs, uint32_t blocks_per_wg, uint32_t G, uint32_t L,
                                                              sgc_table_view lib, uint32_t *__restrict__ counts,
                                                              unsigned long long *__restrict__ matched, uint32_t dbg) {
     constexpr uint32_t S = 1u << LOG2_SLICE;
@@ -178,7 +186,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     __shared__ ulonglong2 tab[S / 2];                        // the slice, bucket by bucket
     __shared__ uint32_t cnt[S];
     __shared__ uint32_t list[K2_LIST];                       // block id << 11 | (fill - 1)
-    __shared__ uint32_t n_list, over_at, miss_cnt[2][K2_U], scratch[128];
+    __shared__ uint32_t miss_cnt[2][K2_U], scratch[128], pre[K2_THREADS], wtmp[17];
     const uint32_t t = threadIdx.x, p = blockIdx.x / G, g = blockIdx.x % G;
     const uint32_t slice = lib.log2_slice < (uint32_t)LOG2_SLICE ? (1u << lib.log2_slice) : S;   // small libraries
     const uint32_t bmask = slice / 2 - 1u, gid_bits = lib.gid_bits;
@@ -196,44 +204,23 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     unsigned long long ts0 = 0, ts_scan = 0, ts_loop = 0;
     uint32_t n_groups_dbg = 0;
     if (dbg & 512) ts0 = __builtin_amdgcn_s_memtime();
-    // The descriptors are scanned in chunks; the blocks of partition p whose id hashes to g are listed (a plain
-    // id % G would hand one workgroup ALL blocks of a partition: K1 opens blocks for the partitions in a
-    // repeating order).  Scanning goes on until the list is half full or the descriptors are exhausted, so that
-    // the software pipeline below runs over one long list (typically all of the workgroup's blocks).  If a
-    // chunk overflows the list (extreme skew), the ids from the first rejected one on are dropped and rescanned.
-    uint32_t win = 0;
-    while (win < n_blocks) {
-        if (t == 0) { n_list = 0; over_at = 0xFFFFFFFFu; }
-        __syncthreads();
-        uint32_t w = win;
-        for (;;) {
-            uint32_t dd[K2_SCAN];                  // all loads of the chunk first (coalesced, in flight together)
-#pragma unroll
-            for (uint32_t k = 0; k < K2_SCAN; k++) {
-                const uint32_t b = w + k * K2_THREADS + t;
-                dd[k] = b < n_blocks ? desc[b] : 0;
-            }
-#pragma unroll
-            for (uint32_t k = 0; k < K2_SCAN; k++) {
-                const uint32_t b = w + k * K2_THREADS + t;
-                if ((dd[k] >> 16) == p + 1 && (dd[k] & DESC_FILL_MASK) && (((b * 0x9E3779B1u) >> 16) & (G - 1u)) == g) {   // G = 2^k
-                    const uint32_t at = atomicAdd(&n_list, 1u);
-                    if (at < K2_LIST) list[at] = (b << 11) | ((dd[k] & DESC_FILL_MASK) - 1u);
-                    else atomicMin(&over_at, b);
-                }
-            }
-            w += K2_SCAN * K2_THREADS;
-            __syncthreads();
-            const bool stop = w >= n_blocks || n_list >= K2_LIST / 2;
-            __syncthreads();
-            if (stop) break;
+    // K1 workgroup w handed this partition wcnt[w][p] blocks, listed in wlist[w][p][]: in that order (w major) the
+    // partition's blocks form one sequence, of which this workgroup takes the g-th of G equal shares — no scan of
+    // the descriptors, and shares that differ by at most one block.
+    uint32_t Bp;
+    pre[t] = wg_scan_1024(t < k1_wgs ? wcnt[t * PART_ARR + p] : 0u, wtmp, &Bp);
+    __syncthreads();
+    const uint32_t s_lo = (uint32_t)((uint64_t)Bp * g / G), s_hi = (uint32_t)((uint64_t)Bp * (g + 1) / G);
+    for (uint32_t win = s_lo; win < s_hi; win += K2_LIST) {
+        const uint32_t nl = s_hi - win < K2_LIST ? s_hi - win : K2_LIST;
+        __syncthreads();                               // the previous round is done with list[]
+        for (uint32_t i = t; i < nl; i += K2_THREADS) {
+            const uint32_t o = win + i, w = find_extent<10>(pre, k1_wgs, o);
+            const uint32_t b = wlist[((size_t)w * PART_ARR + p) * blocks_per_wg + (o - pre[w])];
+            list[i] = (b << 11) | ((desc[b] & DESC_FILL_MASK) - 1u);
         }
-        const uint32_t nl = n_list < K2_LIST ? n_list : K2_LIST, oa = over_at;
-        if (dbg & 512) { ts_scan += __builtin_amdgcn_s_memtime() - ts0; ts0 = __builtin_amdgcn_s_memtime(); n_groups_dbg += (nl + K2_U - 1) / K2_U; }
-        for (uint32_t i = t; i < nl; i += K2_THREADS)
-            if ((list[i] >> 11) >= oa) list[i] = 0xFFFFFFFFu;            // dropped: rescanned in the next round
         __syncthreads();
-        win = w < oa ? w : oa;
+        if (dbg & 512) { ts_scan += __builtin_amdgcn_s_memtime() - ts0; ts0 = __builtin_amdgcn_s_memtime(); n_groups_dbg += (nl + K2_U - 1) / K2_U; }
         // software pipeline over groups of K2_U blocks: `cur` is processed while `nxt` is in flight.  Block ids and
         // fills are wave-uniform (scalar registers).
         uint64_t cur[Q], nxt[Q];
@@ -571,6 +558,7 @@ void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_
     const uint32_t P = 1u << (lib.log2_slots - lib.log2_slice);
     uint64_t tiles = (n + PART_TILE - 1) / PART_TILE;
     if (max_wgs == 0) max_wgs = 256;
+    if (max_wgs > K2_THREADS) max_wgs = K2_THREADS;          // k_count_slices scans one count per K1 workgroup in one go
     uint32_t wgs = (uint32_t)(tiles < max_wgs ? (tiles ? tiles : 1) : max_wgs);
     uint64_t per = (tiles + wgs - 1) / wgs * PART_TILE;                 // records per K1 workgroup, whole tiles
     g->k1_wgs = wgs;
@@ -579,7 +567,9 @@ void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_
     g->n_blocks = wgs * g->blocks_per_wg;
     g->pool_bytes = (uint64_t)g->n_blocks * PART_BLOCK * 8;
     g->desc_tail_off = ((uint64_t)g->n_blocks * 4 + 255) & ~255ull;
-    g->desc_bytes = g->desc_tail_off + SGC_DESC_TAIL;       // k_partition zeroes the tail too
+    g->wcnt_off = g->desc_tail_off + SGC_DESC_TAIL;          // k_partition zeroes the tail and writes every wcnt entry
+    g->wlist_off = (g->wcnt_off + (uint64_t)wgs * PART_ARR * 4 + 255) & ~255ull;
+    g->desc_bytes = g->wlist_off + (uint64_t)wgs * PART_ARR * g->blocks_per_wg * 4;
     g->n_segs = (g->n_blocks + K3_SEG - 1) / K3_SEG;
     g->gids_bytes = (uint64_t)g->n_segs * K3_SEG * PART_BLOCK * 4;
     g->partitions = P;
@@ -589,14 +579,16 @@ void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_
 void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib,
                         const sgc_part_geometry &g, uint64_t *pool, uint32_t *desc) {
     hipLaunchKernelGGL(k_partition, dim3(g.k1_wgs), dim3(K1_THREADS), 0, st, recs, n, g.per_wg, g.blocks_per_wg, L,
-                       lib.log2_slots, lib.log2_slice, pool, desc, (uint32_t *)((char *)desc + g.desc_tail_off), SGC_DESC_TAIL / 4);
+                       lib.log2_slots, lib.log2_slice, pool, desc, (uint32_t *)((char *)desc + g.desc_tail_off), SGC_DESC_TAIL / 4,
+                       (uint32_t *)((char *)desc + g.wcnt_off), (uint32_t *)((char *)desc + g.wlist_off));
 }
 
 void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_part_geometry &g,
                         uint64_t *pool, uint32_t *desc, uint32_t *counts, unsigned long long *matched, uint32_t dbg) {
     const uint32_t G = g.partitions >= 512 ? 1 : 512 / g.partitions;     // two workgroups per CU
     hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE>), dim3(g.partitions * G), dim3(K2_THREADS), 0, st, pool, desc,
-                       g.n_blocks, G, L, lib, counts, matched, dbg);
+                       (const uint32_t *)((const char *)desc + g.wcnt_off), (const uint32_t *)((const char *)desc + g.wlist_off),
+                       g.k1_wgs, g.blocks_per_wg, G, L, lib, counts, matched, dbg);
 }
 
 void sgc_launch_part_k3(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm,
