@@ -393,8 +393,51 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
     c->v_perm = sgc_table_view{nullptr, nullptr, 0, h_lib.gid_bits, 0, 0};
     c->perm_entries = 0;
     if (enable_1mm) {
-        std::vector<uint64_t> child_keys, amb;
-        sgc_build_permute_table(keys, L, h_lib, h_perm, &child_keys, &amb);
+        uint32_t bpk = 8;                    // Bloom bits per child, rounded up to a power-of-two word count: 6.0 M children -> 8 MiB
+        if (const char *v = getenv("SGC_PERM_BLOOM_BITS")) bpk = (uint32_t)std::max(1, atoi(v));
+        const uint64_t n_children = (uint64_t)n * 3 * L;
+        const uint32_t bloom_log2 = sgc_bloom_log2_words(n_children, bpk, 10, 24);
+        std::vector<uint64_t> amb;
+        const bool device_build = h_lib.gid_bits != 0 && !getenv("SGC_HOST_BUILD");
+        if (device_build) {
+            // children, their table, its filter and the ambiguity masks are built on the GPU (sgc_build.hip)
+            const uint32_t pl2 = sgc_permute_log2_slots(n_children);
+            uint64_t *d_keys = nullptr; void *d_scr = nullptr; unsigned long long *d_ent = nullptr;
+            auto drop = [&]() { if (d_keys) hipFree(d_keys); if (d_scr) hipFree(d_scr); if (d_ent) hipFree(d_ent); };
+            hipError_t e = hipMalloc((void **)&d_keys, (size_t)n * 8);
+            if (e == hipSuccess) e = hipMalloc(&d_scr, sgc_device_build_scratch_bytes(n, L));
+            if (e == hipSuccess) e = hipMalloc((void **)&d_ent, 8);
+            if (e == hipSuccess) e = hipMalloc((void **)&c->d_perm_slots, sizeof(uint64_t) << pl2);
+            if (e == hipSuccess) e = hipMalloc((void **)&c->d_bloom_perm, sizeof(uint64_t) << bloom_log2);
+            if (e == hipSuccess) e = hipMalloc((void **)&c->d_amb, (size_t)n * 16);
+            if (e == hipSuccess) e = hipMemcpyAsync(d_keys, keys.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(c->d_perm_slots, 0xFF, sizeof(uint64_t) << pl2, c->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(c->d_bloom_perm, 0, sizeof(uint64_t) << bloom_log2, c->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(c->d_amb, 0, (size_t)n * 16, c->stream);
+            if (e == hipSuccess) e = hipMemsetAsync(d_ent, 0, 8, c->stream);
+            if (e != hipSuccess) { drop(); free_tables(c); return fail(e == hipErrorOutOfMemory ? SGC_E_OOM : SGC_E_HIP, std::string("sgc_set_library: ") + hipGetErrorString(e)); }
+            if (sgc_device_build_permute(c->stream, d_keys, n, L, c->v_lib, c->d_perm_slots, pl2, h_lib.gid_bits, c->d_bloom_perm,
+                                         bloom_log2, c->d_amb, d_ent, d_scr) != 0) {
+                drop(); free_tables(c);
+                return fail(SGC_E_HIP, "sgc_set_library: device build of the single-mismatch table failed");
+            }
+            unsigned long long ent = 0;
+            e = hipMemcpyAsync(&ent, d_ent, 8, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            drop();
+            if (e != hipSuccess) { free_tables(c); return fail(SGC_E_HIP, std::string("sgc_set_library: ") + hipGetErrorString(e)); }
+            c->perm_entries = ent;
+            c->v_perm = sgc_table_view{c->d_perm_slots, nullptr, pl2, h_lib.gid_bits, pl2, 0};
+            c->b_perm.words = c->d_bloom_perm; c->b_perm.log2_words = bloom_log2; c->b_perm.pad_ = 0;
+        } else {
+            std::vector<uint64_t> child_keys;
+            sgc_build_permute_table(keys, L, h_lib, h_perm, &child_keys, &amb);
+            rc = upload_table(h_perm, &c->d_perm_slots, &c->d_perm_vals, &c->v_perm, c->stream);
+            if (rc != SGC_OK) { free_tables(c); return rc; }
+            c->perm_entries = h_perm.entries;
+            rc = upload_bloom(child_keys, bloom_log2, &c->d_bloom_perm, &c->b_perm, c->stream);
+            if (rc != SGC_OK) { free_tables(c); return rc; }
+        }
         // core indexes (variant 4): span bases [2, L) cut in two; absent => the probing resolver stays in charge
         if (L >= 4 && L <= SGC_REC8_MAXL && h_lib.gid_bits != 0) {
             const uint32_t ca = (L - 2) / 2;
@@ -409,23 +452,15 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
                     HIP_TRY(hipMemcpyAsync(c->d_core_starts[k], hc[k].starts.data(), hc[k].starts.size() * 2, hipMemcpyHostToDevice, c->stream));
                     c->v_core[k] = sgc_core_view{c->d_core_ents[k], c->d_core_gids[k], c->d_core_starts[k], hc[k].log2_p, hc[k].cs, hc[k].cl, 0};
                 }
-                HIP_TRY(hipMalloc((void **)&c->d_amb, amb.size() * 8));
-                HIP_TRY(hipMemcpyAsync(c->d_amb, amb.data(), amb.size() * 8, hipMemcpyHostToDevice, c->stream));
+                if (!device_build) {
+                    HIP_TRY(hipMalloc((void **)&c->d_amb, amb.size() * 8));
+                    HIP_TRY(hipMemcpyAsync(c->d_amb, amb.data(), amb.size() * 8, hipMemcpyHostToDevice, c->stream));
+                }
                 HIP_TRY(hipStreamSynchronize(c->stream));
                 c->has_core = true;
                 if (getenv("SGC_OCC_DBG")) sgc_core_print_occupancy();
             }
         }
-        rc = upload_table(h_perm, &c->d_perm_slots, &c->d_perm_vals, &c->v_perm, c->stream);
-        if (rc != SGC_OK) { free_tables(c); return rc; }
-        c->perm_entries = h_perm.entries;
-        {
-            uint32_t bpk = 8;                    // bits per child, rounded up to a power-of-two word count: 6.0 M children -> 8 MiB
-            if (const char *v = getenv("SGC_PERM_BLOOM_BITS")) bpk = (uint32_t)std::max(1, atoi(v));
-            rc = upload_bloom(child_keys, sgc_bloom_log2_words(child_keys.size(), bpk, 10, 24), &c->d_bloom_perm, &c->b_perm,
-                              c->stream);
-        }
-        if (rc != SGC_OK) { free_tables(c); return rc; }
     }
     c->n = n; c->L = L; c->one_mm = enable_1mm != 0; c->rec16 = L > SGC_REC8_MAXL; c->has_lib = true;
     return SGC_OK;

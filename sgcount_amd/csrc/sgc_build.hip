@@ -1,0 +1,94 @@
+// sgc_build.hip — device-side construction of the single-mismatch table (Permuter::build, reference
+// src/permutes.rs:63-158, restricted to what Counter::assign can observe), its Bloom filter and the per-guide
+// ambiguity masks of the core resolver.  gfx950.
+//
+// The host version (sgc_tables.cpp sgc_build_permute_table) spends ~0.6 s on 6 M children of a 100k-guide
+// library — the largest fixed cost of a short run.  Here: one kernel writes every (child, parent) pair, rocPRIM
+// sorts the pairs by child, and a second kernel looks at each child's neighbours in the sorted order:
+//   alone and not a library member  -> the child has exactly one parent: insert (child -> parent) into the
+//                                      open-addressed table (atomicCAS on the slots), set its Bloom bits
+//   otherwise                        -> two or more parents (src/permutes.rs:127-144 moves it to `null`), or a
+//                                      library member: set the ambiguity bit (4 j + b) of every parent
+// Insertion order is whatever the race gives; a lookup scans from the home bucket to the first free slot, which
+// is independent of that order.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string.h>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "sgc_device.h"
+#include "sgc_format.h"
+#include "sgc_kernels.h"
+
+__global__ void __launch_bounds__(256) k_gen_children(const uint64_t *__restrict__ keys, uint32_t n, uint32_t L,
+                                                      uint64_t *__restrict__ ck, uint32_t *__restrict__ cg) {
+    const uint64_t total = (uint64_t)n * 3 * L;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t g = (uint32_t)(i / (3 * L)), r = (uint32_t)(i % (3 * L)), j = r / 3;
+        const uint64_t d = r % 3 + 1;                       // 3 ACGT substitutions per position
+        ck[i] = keys[g] ^ (d << (2 * j));
+        cg[i] = g;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_finish_children(const uint64_t *__restrict__ ck, const uint32_t *__restrict__ cg,
+                                                         uint64_t total, const uint64_t *__restrict__ keys,
+                                                         sgc_table_view lib, uint64_t *__restrict__ slots,
+                                                         uint32_t log2_slots, uint32_t gid_bits, uint64_t *__restrict__ bloom,
+                                                         uint32_t bloom_log2, unsigned long long *__restrict__ amb,
+                                                         unsigned long long *__restrict__ n_entries) {
+    uint32_t mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = ck[i];
+        const uint32_t g = cg[i];
+        const bool dup = (i > 0 && ck[i - 1] == k) || (i + 1 < total && ck[i + 1] == k);
+        if (!dup && table_find<true>(lib, k) == SGC_NONE) {
+            const uint64_t packed = (k << gid_bits) | g;
+            uint32_t b = sgc_home_bucket(k, log2_slots);
+            for (;;) {
+                if (atomicCAS((unsigned long long *)&slots[2ull * b], (unsigned long long)SGC_EMPTY, (unsigned long long)packed) == SGC_EMPTY) break;
+                if (atomicCAS((unsigned long long *)&slots[2ull * b + 1], (unsigned long long)SGC_EMPTY, (unsigned long long)packed) == SGC_EMPTY) break;
+                b = sgc_next_bucket(b, log2_slots);
+            }
+            const uint64_t h = sgc_hash2(k);
+            atomicOr((unsigned long long *)&bloom[sgc_bloom_word(h, bloom_log2)], (unsigned long long)sgc_bloom_mask(h));
+            mine++;
+        } else {
+            const uint64_t x = k ^ keys[g];                 // one differing base
+            const uint32_t j = (uint32_t)__builtin_ctzll(x) >> 1, bit = 4 * j + (uint32_t)((k >> (2 * j)) & 3);
+            atomicOr(&amb[2ull * g + (bit >> 6)], 1ull << (bit & 63));
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(n_entries, (unsigned long long)mine);
+}
+
+// d_slots: 2^log2_slots u64 preset to SGC_EMPTY; d_bloom: 2^bloom_log2 u64 of zeros; d_amb: 2 n u64 of zeros;
+// d_scratch: sgc_device_build_scratch_bytes(n, L) bytes.  Asynchronous on `st`; *d_entries (a device counter,
+// zeroed by the caller) receives the number of table entries.
+size_t sgc_device_build_scratch_bytes(uint32_t n, uint32_t L) {
+    const size_t total = (size_t)n * 3 * L;
+    size_t tmp = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                    total, 0, 2 * L, (hipStream_t)0);
+    return total * (8 + 8 + 4 + 4) + ((tmp + 255) & ~(size_t)255) + 1024;
+}
+
+int sgc_device_build_permute(hipStream_t st, const uint64_t *d_keys, uint32_t n, uint32_t L, const sgc_table_view &lib,
+                             uint64_t *d_slots, uint32_t log2_slots, uint32_t gid_bits, uint64_t *d_bloom,
+                             uint32_t bloom_log2, uint64_t *d_amb, unsigned long long *d_entries, void *d_scratch) {
+    const size_t total = (size_t)n * 3 * L;
+    uint64_t *ck_in = (uint64_t *)d_scratch, *ck_out = ck_in + total;
+    uint32_t *cg_in = (uint32_t *)(ck_out + total), *cg_out = cg_in + total;
+    void *tmp = (void *)(((uintptr_t)(cg_out + total) + 255) & ~(uintptr_t)255);
+    size_t tmp_bytes = 0;
+    if (rocprim::radix_sort_pairs(nullptr, tmp_bytes, ck_in, ck_out, cg_in, cg_out, total, 0, 2 * L, st) != hipSuccess) return -1;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_gen_children, dim3(grid), dim3(256), 0, st, d_keys, n, L, ck_in, cg_in);
+    if (rocprim::radix_sort_pairs(tmp, tmp_bytes, ck_in, ck_out, cg_in, cg_out, total, 0, 2 * L, st) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_finish_children, dim3(grid), dim3(256), 0, st, ck_out, cg_out, (uint64_t)total, d_keys, lib, d_slots,
+                       log2_slots, gid_bits, d_bloom, bloom_log2, (unsigned long long *)d_amb, d_entries);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

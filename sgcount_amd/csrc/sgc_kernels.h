@@ -74,6 +74,12 @@ void sgc_launch_core(hipStream_t st, uint32_t L, const sgc_table_view &lib, cons
 
 void sgc_core_print_occupancy();
 
+// ---- device-side build of the single-mismatch table, its Bloom filter and the ambiguity masks (sgc_build.hip)
+size_t sgc_device_build_scratch_bytes(uint32_t n, uint32_t L);
+int sgc_device_build_permute(hipStream_t st, const uint64_t *d_keys, uint32_t n, uint32_t L, const sgc_table_view &lib,
+                             uint64_t *d_slots, uint32_t log2_slots, uint32_t gid_bits, uint64_t *d_bloom,
+                             uint32_t bloom_log2, uint64_t *d_amb, unsigned long long *d_entries, void *d_scratch);
+
 // ---- FASTQ ingest (sgc_fastq.hip) -----------------------------------------------------------------
 // tile_scratch: sgc_fastq_tiles(n) + 1 u32; after the call tile_scratch[tiles] = number of '\n' in the text
 uint32_t sgc_fastq_tiles(uint64_t n);

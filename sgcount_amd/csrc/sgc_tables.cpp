@@ -126,6 +126,10 @@ uint32_t sgc_bloom_log2_words(uint64_t n_keys, uint32_t bits_per_key, uint32_t m
     return std::min(std::max(l, min_log2), max_log2);
 }
 
+uint32_t sgc_permute_log2_slots(uint64_t n_children) {
+    return std::max<uint32_t>(4, ceil_log2((uint64_t)((double)n_children / 0.5) + 1));
+}
+
 void sgc_build_permute_table(const std::vector<uint64_t> &keys, uint32_t L, const sgc_host_table &lib,
                              sgc_host_table &out, std::vector<uint64_t> *child_keys, std::vector<uint64_t> *amb) {
     const uint32_t n = (uint32_t)keys.size();

@@ -46,6 +46,9 @@ struct sgc_host_core {
 };
 bool sgc_build_core_index(const std::vector<uint64_t> &keys, uint32_t L, uint32_t cs, uint32_t cl, sgc_host_core &out);
 
+// log2 of the slot count of a single-mismatch table sized for n_children (all 3 L children per guide; load <= 0.5)
+uint32_t sgc_permute_log2_slots(uint64_t n_children);
+
 // Blocked Bloom filter over `keys` with 2^log2_words 64-bit words (sgc_format.h sgc_bloom_*).
 void sgc_build_bloom(const std::vector<uint64_t> &keys, uint32_t log2_words, std::vector<uint64_t> &out);
 uint32_t sgc_bloom_log2_words(uint64_t n_keys, uint32_t bits_per_key, uint32_t min_log2, uint32_t max_log2);

@@ -310,6 +310,41 @@ def test_core_index_overflow_falls_back(S):
     assert other.device(True).info().core_partitions >= 1
 
 
+def test_device_build_matches_host_build(S, monkeypatch):
+    """The single-mismatch table built on the GPU (children -> rocPRIM sort -> CAS inserts, sgc_build.hip) answers
+    every probe like the host-built one (sgc_tables.cpp) and like the oracle's Permuter, and holds as many entries."""
+    rng = random.Random(2024)
+    guides, _ = _random_case(rng, 14, 400, 1, 3)
+    lib_text = _fasta(guides)
+    probes = set(guides)
+    for g in guides[:120]:
+        for j in range(14):
+            for b in b"ACGT":
+                w = bytearray(g); w[j] = b
+                probes.add(bytes(w))
+    for _ in range(3000):
+        probes.add(bytes(rng.choice(b"ACGT") for _ in range(14)))
+    probes = sorted(probes)
+    olib = O.Library(lib_text)
+    operm = O.Permuter(olib)
+    index = {g: i for i, g in enumerate(guides)}
+    want = []
+    for w in probes:
+        parent = operm.contains(w) if w not in index else None      # the permuter is consulted after the library (counter.rs:113)
+        want.append(index[parent] if parent is not None else -1)
+    got, entries = {}, {}
+    for mode in ("device", "host"):
+        if mode == "host":
+            monkeypatch.setenv("SGC_HOST_BUILD", "1")
+        lib = _lib(S, lib_text)
+        dev = lib.device(True)
+        out = dev.lookup(probes, which=1).tolist()
+        got[mode] = [(-1 if w in index else v) for w, v in zip(probes, out)]     # children that are guides are unreachable
+        entries[mode] = dev.info().perm_entries
+    assert got["device"] == got["host"] == want
+    assert entries["device"] == entries["host"] > 0
+
+
 def test_duplicate_ids_pool_counts(S):
     """counter.rs:232-235 folds by id: two guides sharing an id report the pooled count on both rows"""
     lib_text = b">same\nACGTAC\n>same\nTTGCAA\n>other\nCCCCCC\n"
