@@ -8,18 +8,19 @@
 //   Cut them into two disjoint CORES, A = [2, 2+a) and B = [2+a, L).  A window that is within one
 //   substitution of a guide agrees with it on core A or on core B (or both).  So: partition the unresolved
 //   records by the hash of their core-A bases; a workgroup stages the guides whose core-A bases (at each of
-//   the three alignments) hash to its partition — a few thousand 8-byte entries — and every record meets,
-//   in one short probe chain, ALL guides that agree with any of its windows on core A.  XOR + popcount
-//   gives the Hamming distance: 0 = exact (src/counter.rs:111), 1 = a parent of the window's child
-//   (src/counter.rs:113-116).  What pass A cannot see (a substitution inside core A) pass B sees, the same
-//   kernel over core B.
+//   the three alignments) hash to its partition — about a thousand 8-byte entries (core value | alignment,
+//   the guide's other bases closed up into 32 bits), bucketed CSR-style — and every record meets, in one
+//   short bucket scan, ALL guides that agree with any of its windows on core A.  XOR + popcount of the
+//   32-bit "rest" gives the Hamming distance: 0 = exact (src/counter.rs:111), 1 = a parent of the window's
+//   child (src/counter.rs:113-116).  What pass A cannot see (a substitution inside core A) pass B sees,
+//   the same kernel over core B.
 //
 //   Uniqueness (src/permutes.rs:127-144: a child with two parents maps to nothing): the parents whose
-//   substitution lies outside the pass's core all sit in the chain and are counted; a parent with its
+//   substitution lies outside the pass's core all sit in the bucket and are counted; a parent with its
 //   substitution inside the core is invisible, so for a single visible parent one bit of a per-guide mask
-//   (sgc_tables.cpp: amb, bit 4j+b = "child (j, b) of this guide has another parent") decides.  A window
-//   with an 'N' at j needs no mask: it is resolved by the pass whose core does not hold j, where every
-//   guide that agrees on all other positions is in the chain.
+//   (amb, built by sgc_build.hip / sgc_tables.cpp: bit 4j+b = "child (j, b) of this guide has another
+//   parent") decides.  A window with an 'N' at j needs no mask: it is resolved by the pass whose core does
+//   not hold j, where every guide that agrees on all other positions is in the bucket.
 //
 //   Order (src/counter.rs:111-135): C-exact, C-1mm, P-exact, P-1mm, M-exact, M-1mm.  Pass A takes the first
 //   level it can prove; if a higher single-mismatch level is still undecided (nothing seen in A) the
@@ -43,7 +44,7 @@
 #define CP_SEG 1024u             // extents scanned per segment
 #define CP_MAXP (1u << SGC_CORE_MAX_LOG2_P)
 #define CP_DROP 0xFFFFu
-#define CP_CUR_STRIDE 32u         // one 128-byte line per partition cursor: atomics on one line serialise
+#define CP_CUR_STRIDE 32u         // one 128-byte line per partition cursor
 #define KC_THREADS 1024u
 #define KC_CHUNK 4096u           // records per unit of resolver work
 #define KC_GRID 512u
