@@ -70,7 +70,7 @@ def _host_needs_build(out):
 def build_host(force=False, verbose=False):
     """C++ host side (FASTX reader, offsetter, gene map, results, CLI) — plain g++ over the C ABI."""
     cxx = shutil.which("g++") or "g++"
-    common = ["-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-pthread"]
+    common = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-pthread"]
     link = ["-L" + PKG, "-lsgcount_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + PKG]
     srcs = [os.path.join(CSRC, f) for f in HOST_SRCS]
     if force or _host_needs_build(HOST_SO):

@@ -335,44 +335,95 @@ static void sgc_check(int rc, const char *what) {
 // FASTQ at speed (replaces fxread for the count loop): the host only inflates/reads text and cuts it at record
 // boundaries by counting newlines; record boundaries inside a chunk, window extraction and packing happen on
 // the GPU (sgc_sample_push_fastq).  Two pinned buffers alternate so that reading chunk k+1 overlaps counting k.
+// Number of '\n' in [p, p + n): byte compares summed in 8-bit lanes (the compiler turns the inner loop into vector
+// compares; 255 iterations cannot overflow a lane), flushed to a wide sum.
+static size_t count_newlines(const uint8_t *p, size_t n) {
+    size_t total = 0;
+    while (n) {
+        const size_t m = std::min<size_t>(n, 255 * 64);
+        uint8_t acc[64] = {0};
+        size_t i = 0;
+        for (; i + 64 <= m; i += 64)
+            for (int k = 0; k < 64; k++) acc[k] += (uint8_t)(p[i + k] == '\n');
+        for (; i < m; i++) total += p[i] == '\n';
+        for (int k = 0; k < 64; k++) total += acc[k];
+        p += m; n -= m;
+    }
+    return total;
+}
+
+// Byte source of the text path: a plain file is read with read(2) straight into the caller's (pinned) buffer; a
+// gzip stream (magic 1f 8b) goes through zlib.
+struct TextSource {
+    FILE *fp = nullptr;
+    gzFile gz = nullptr;
+    explicit TextSource(const std::string &path) {
+        fp = fopen(path.c_str(), "rb");
+        if (!fp) throw Error("No such file or directory (os error 2): " + path);
+        unsigned char magic[2] = {0, 0};
+        const size_t got = fread(magic, 1, 2, fp);
+        if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+            fclose(fp); fp = nullptr;
+            gz = gzopen(path.c_str(), "rb");
+            if (!gz) throw Error("No such file or directory (os error 2): " + path);
+            gzbuffer(gz, 1u << 20);
+        } else {
+            rewind(fp);
+            setvbuf(fp, nullptr, _IONBF, 0);             // unbuffered: fread becomes read(2) into our buffer
+        }
+    }
+    ~TextSource() { if (fp) fclose(fp); if (gz) gzclose(gz); }
+    // up to n bytes; 0 = end of stream
+    size_t read(uint8_t *dst, size_t n, const std::string &path) {
+        if (gz) {
+            const int got = gzread(gz, dst, (unsigned)std::min<size_t>(n, 1u << 30));
+            if (got < 0) throw Error("read error in " + path);
+            return (size_t)got;
+        }
+        const size_t got = fread(dst, 1, n, fp);
+        if (got == 0 && ferror(fp)) throw Error("read error in " + path);
+        return got;
+    }
+};
+
 static bool count_fastq_text(sgc_sample *smp, const std::string &path, const CountOptions &opt) {
-    gzFile f = gzopen(path.c_str(), "rb");
-    if (!f) throw Error("No such file or directory (os error 2): " + path);
-    struct FGuard { gzFile f; ~FGuard() { gzclose(f); } } fg{f};
-    gzbuffer(f, 1u << 20);
-    const int first = gzgetc(f);
-    if (first != '@') return false;                      // not FASTQ: the caller uses the record reader
-    gzungetc(first, f);
+    TextSource src(path);
     const size_t cap = std::max<size_t>(opt.chunk_bytes, 1u << 16);
     uint8_t *buf[2] = {(uint8_t *)sgc_alloc_pinned(cap), (uint8_t *)sgc_alloc_pinned(cap)};
     struct BGuard { uint8_t **b; ~BGuard() { sgc_free_pinned(b[0]); sgc_free_pinned(b[1]); } } bg{buf};
     if (!buf[0] || !buf[1]) throw Error("cannot allocate pinned host buffers");
     size_t have = 0;                                     // bytes carried over (an incomplete record)
     int cur = 0;
-    bool eof = false;
+    bool eof = false, first_chunk = true;
     while (!eof || have) {
         while (have < cap && !eof) {
-            const int got = gzread(f, buf[cur] + have, (unsigned)std::min<size_t>(cap - have, 1u << 30));
-            if (got < 0) throw Error("read error in " + path);
+            const size_t got = src.read(buf[cur] + have, cap - have, path);
             if (got == 0) eof = true;
-            have += (size_t)got;
+            have += got;
         }
-        // cut after the last newline that completes a whole number of 4-line records
-        size_t lines = 0, cut = 0;
-        const uint8_t *p = buf[cur], *end = buf[cur] + have;
-        while (p < end) {
-            const uint8_t *nl = (const uint8_t *)memchr(p, '\n', (size_t)(end - p));
-            if (!nl) break;
-            lines++;
-            p = nl + 1;
-            if ((lines & 3) == 0) cut = (size_t)(p - buf[cur]);
+        if (first_chunk) {
+            if (!have || buf[cur][0] != '@') return false;    // not FASTQ: the caller uses the record reader
+            first_chunk = false;
         }
+        // cut after the last newline that completes a whole number of 4-line records: count the newlines, then step
+        // back over the (count mod 4) that belong to the incomplete record
+        const size_t lines = count_newlines(buf[cur], have);
+        size_t cut = have;
         if (eof) {                                       // final chunk: an unterminated last line is allowed
             const size_t tail_lines = lines + (have && buf[cur][have - 1] != '\n' ? 1 : 0);
             if (tail_lines % 4 != 0) throw Panic("truncated FASTQ record in " + path);
-            cut = have;
-        } else if (cut == 0) {
-            throw Error("FASTQ record larger than the text chunk in " + path);
+        } else {
+            size_t back = lines & 3, end = have;
+            // the bytes after the last newline are an incomplete line; then `back` complete lines more
+            for (;;) {
+                const void *nl = end ? memrchr(buf[cur], '\n', end) : nullptr;
+                if (!nl) { end = 0; break; }
+                end = (size_t)((const uint8_t *)nl - buf[cur]);      // index of that newline
+                if (back == 0) { end += 1; break; }
+                back--;
+            }
+            cut = end;
+            if (cut == 0) throw Error("FASTQ record larger than the text chunk in " + path);
         }
         if (cut) {
             sgc_check(sgc_sample_sync(smp), "sgc_sample_sync");          // the other buffer's count pass may still be running
