@@ -55,17 +55,18 @@ class DeviceWorkload:
         self.export = torch.zeros(n_guides + 2, dtype=torch.int64, device=self.dev)
 
     # one pass of the hot path over the whole resident sample; leaves counts|total|matched in self.export
-    def step(self, first=0, n=None):
+    def step(self, first=0, n=None, out=None):
+        """out: an int64 device tensor of n_guides + 2 words to receive the row instead of self.export"""
         n = self.n_reads - first if n is None else n
         _ffi.check(self.abi.sgc_sample_reset(self.sample))
         _ffi.check(self.abi.sgc_sample_push_packed(self.sample, self.records.data_ptr() + first * self.words * 8, n,
                                                    _ffi.MEM_DEVICE))
-        _ffi.check(self.abi.sgc_sample_export_device(self.sample, self.export.data_ptr()))
+        _ffi.check(self.abi.sgc_sample_export_device(self.sample, (self.export if out is None else out).data_ptr()))
 
-    def result(self):
+    def result(self, row=None):
         """(counts np.uint64[n_guides], total, matched) of the last step (synchronises)."""
         self.torch.cuda.synchronize()
-        host = self.export.cpu().numpy().view(np.uint64)
+        host = (self.export if row is None else row).cpu().numpy().view(np.uint64)
         return host[: self.n_guides].copy(), int(host[self.n_guides]), int(host[self.n_guides + 1])
 
     def close(self):
