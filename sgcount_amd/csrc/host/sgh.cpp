@@ -386,6 +386,28 @@ struct TextSource {
     }
 };
 
+// Where to cut a chunk of FASTQ text so that it holds whole 4-line records: count the newlines, then step back over
+// the (count mod 4) complete lines — and the unterminated one — that belong to the record the chunk ends inside.
+// The final chunk (eof) is taken whole; its last line may lack the newline.
+size_t fastq_chunk_cut(const uint8_t *buf, size_t have, bool eof, const std::string &path) {
+    const size_t lines = count_newlines(buf, have);
+    if (eof) {
+        const size_t tail_lines = lines + (have && buf[have - 1] != '\n' ? 1 : 0);
+        if (tail_lines % 4 != 0) throw Panic("truncated FASTQ record in " + path);
+        return have;
+    }
+    size_t back = lines & 3, end = have;
+    for (;;) {
+        const void *nl = end ? memrchr(buf, '\n', end) : nullptr;
+        if (!nl) { end = 0; break; }
+        end = (size_t)((const uint8_t *)nl - buf);           // index of that newline
+        if (back == 0) { end += 1; break; }
+        back--;
+    }
+    if (end == 0) throw Error("FASTQ record larger than the text chunk in " + path);
+    return end;
+}
+
 static bool count_fastq_text(sgc_sample *smp, const std::string &path, const CountOptions &opt) {
     TextSource src(path);
     const size_t cap = std::max<size_t>(opt.chunk_bytes, 1u << 16);
@@ -405,26 +427,7 @@ static bool count_fastq_text(sgc_sample *smp, const std::string &path, const Cou
             if (!have || buf[cur][0] != '@') return false;    // not FASTQ: the caller uses the record reader
             first_chunk = false;
         }
-        // cut after the last newline that completes a whole number of 4-line records: count the newlines, then step
-        // back over the (count mod 4) that belong to the incomplete record
-        const size_t lines = count_newlines(buf[cur], have);
-        size_t cut = have;
-        if (eof) {                                       // final chunk: an unterminated last line is allowed
-            const size_t tail_lines = lines + (have && buf[cur][have - 1] != '\n' ? 1 : 0);
-            if (tail_lines % 4 != 0) throw Panic("truncated FASTQ record in " + path);
-        } else {
-            size_t back = lines & 3, end = have;
-            // the bytes after the last newline are an incomplete line; then `back` complete lines more
-            for (;;) {
-                const void *nl = end ? memrchr(buf[cur], '\n', end) : nullptr;
-                if (!nl) { end = 0; break; }
-                end = (size_t)((const uint8_t *)nl - buf[cur]);      // index of that newline
-                if (back == 0) { end += 1; break; }
-                back--;
-            }
-            cut = end;
-            if (cut == 0) throw Error("FASTQ record larger than the text chunk in " + path);
-        }
+        const size_t cut = fastq_chunk_cut(buf[cur], have, eof, path);
         if (cut) {
             sgc_check(sgc_sample_sync(smp), "sgc_sample_sync");          // the other buffer's count pass may still be running
             sgc_check(sgc_sample_push_fastq(smp, buf[cur], cut, SGC_MEM_HOST, nullptr), "sgc_sample_push_fastq");

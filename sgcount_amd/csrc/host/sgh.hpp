@@ -93,6 +93,8 @@ struct CountOptions {
     size_t batch_reads = 1u << 20;
 };
 void count(const CountOptions &opt);                     // count.rs:74-148
+// text path of count(): byte offset at which a chunk of FASTQ text ends on a whole 4-line record (exposed for tests)
+size_t fastq_chunk_cut(const uint8_t *buf, size_t have, bool eof, const std::string &path);
 int cli_main(int argc, char **argv);                     // main.rs:142-203; returns the process exit code
 
 }  // namespace sgh

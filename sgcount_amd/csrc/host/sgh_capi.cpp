@@ -129,4 +129,9 @@ int sgh_fastx_stats(const char *path, uint64_t *n_records, uint64_t *seq_bytes, 
     });
 }
 
+// the text path's chunk cutter (sgh.cpp fastq_chunk_cut): cut_out = bytes that form whole 4-line records
+int sgh_fastq_chunk_cut(const uint8_t *buf, uint64_t have, int eof, uint64_t *cut_out) {
+    return guard([&] { *cut_out = sgh::fastq_chunk_cut(buf, (size_t)have, eof != 0, "<buffer>"); });
+}
+
 }  // extern "C"

@@ -27,7 +27,7 @@ def load():
         L.sgh_last_error.restype = C.c_char_p
         for name in ("sgh_cli", "sgh_entropy_offset_group", "sgh_positional_entropy", "sgh_minimize_mse",
                      "sgh_generate_sample_names", "sgh_genemap_get", "sgh_genemap_missing", "sgh_generate_columns",
-                     "sgh_format_results", "sgh_library_info", "sgh_fastx_stats"):
+                     "sgh_format_results", "sgh_library_info", "sgh_fastx_stats", "sgh_fastq_chunk_cut"):
             getattr(L, name).restype = C.c_int
         _lib = L
     return _lib
@@ -115,6 +115,13 @@ def fastx_stats(path):
     a, b, c = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
     _chk(load().sgh_fastx_stats(path.encode(), C.byref(a), C.byref(b), C.byref(c)))
     return a.value, b.value, c.value
+
+
+def fastq_chunk_cut(buf: bytes, eof: bool):
+    """Bytes of `buf` that form whole 4-line FASTQ records (the text path's chunk cutter)."""
+    out = C.c_uint64()
+    _chk(load().sgh_fastq_chunk_cut(buf, len(buf), int(eof), C.byref(out)))
+    return out.value
 
 
 def cli(argv):

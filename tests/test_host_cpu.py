@@ -166,3 +166,48 @@ def test_results_match_oracle(H, tmp_path):
     with pytest.raises(H.HostError) as e:                                                            # results.rs:59
         H.format_results(lp, [[1] * 101], ["s"], b"gene.0\tlib.0\n", True)
     assert e.value.code == 101
+
+
+def test_fastq_chunk_cut_matches_line_walk():
+    """The text path cuts chunks with a vectorised newline count + memrchr; a plain line walk must agree, on
+    texts whose quality lines hold '@' and '+', with and without a trailing newline, cut anywhere."""
+    import random
+    from sgcount_amd import hostlib
+    rng = random.Random(31)
+    recs = []
+    for i in range(300):
+        n = rng.randrange(0, 90)
+        seq = bytes(rng.choice(b"ACGTN") for _ in range(n))
+        qual = bytes(rng.choice(b"@+I#5") for _ in range(n))
+        recs.append(b"@r%d\n%s\n+\n%s\n" % (i, seq, qual))
+    text = b"".join(recs)
+
+    def walk(buf):
+        lines, cut, pos = 0, 0, 0
+        while True:
+            nl = buf.find(b"\n", pos)
+            if nl < 0:
+                break
+            lines += 1
+            pos = nl + 1
+            if lines % 4 == 0:
+                cut = pos
+        return cut
+    for _ in range(400):
+        end = rng.randrange(1, len(text) + 1)
+        buf = text[:end]
+        want = walk(buf)
+        if want == 0:
+            with pytest.raises(hostlib.HostError):
+                hostlib.fastq_chunk_cut(buf, False)
+        else:
+            assert hostlib.fastq_chunk_cut(buf, False) == want
+    # final chunk: whole records pass with or without the last newline, a torn record is a panic (code 101)
+    assert hostlib.fastq_chunk_cut(text, True) == len(text)
+    assert hostlib.fastq_chunk_cut(text[:-1], True) == len(text) - 1
+    with pytest.raises(hostlib.HostError) as e:
+        hostlib.fastq_chunk_cut(text[: len(text) - len(recs[-1]) + 5], True)
+    assert e.value.code == 101
+    # long runs: the 8-bit lane accumulators of the newline counter are flushed before they can wrap
+    big = b"\n" * (255 * 64 * 3 + 17) + b"x"
+    assert hostlib.fastq_chunk_cut(big, False) == (255 * 64 * 3 + 17) // 4 * 4
