@@ -33,7 +33,7 @@
 #endif
 #define PART_TILE (K1_THREADS * 8u) // records staged per tile in K1 (8 per lane)
 #define PART_BLOCK 1024u         // records per block (small blocks: fewer empty slots in the open blocks K1 leaves)
-#define PART_MAXP 64u            // max library slices; partition index PART_MAXP' = P_lib is the generic one
+#define PART_MAXP 128u           // max library slices (~210k guides); partition index P_lib is the generic one
 #define PART_ARR (PART_MAXP + 1u)
 #define DESC_FILL_MASK 0xFFFFu
 
@@ -93,24 +93,30 @@ __global__ void __launch_bounds__(K1_THREADS) k_partition(const uint64_t *__rest
         // one lane per partition: exclusive scan of the tile counts, and where the tile's run goes.  A run
         // first tops up the partition's open block, the remainder opens a new one, so every closed block is
         // full and a workgroup never needs more than per_wg / BLOCK + P blocks.
-        if (t < 64 || t == 64) {
-            // lanes 0..63: library slices (scanned by wave 0); lane 64 (wave 1): the generic partition, which
-            // starts where the slices end
-            const uint32_t q = t < 64 ? t : P;
-            const uint32_t c = (t < P || t == 64) ? cnt[q] : 0;
+        if (t < 64 || (t < PART_MAXP && P > 64) || t == PART_MAXP) {
+            // lanes 0..127: library slices (scanned by wave 0, and by wave 1 when there are more than 64: it adds the
+            // first 64 counts up for its base); lane 128 (wave 2): the generic partition, which starts where the
+            // slices end
+            const uint32_t q = t < PART_MAXP ? t : P, lane = t & 63u;
+            const uint32_t c = (t < P || t == PART_MAXP) ? cnt[q] : 0;
             uint32_t st0;
-            if (t < 64) {
-                uint32_t incl = c;
+            if (t < PART_MAXP) {
+                uint32_t incl = c, base = 0;
 #pragma unroll
                 for (int off = 1; off < 64; off <<= 1) {
                     const uint32_t v = __shfl_up(incl, off, 64);
-                    if ((int)t >= off) incl += v;
+                    if ((int)lane >= off) incl += v;
                 }
-                st0 = incl - c;
+                if (t >= 64) {                           // wave 1: total of slices 0..63
+                    base = cnt[lane];
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) base += __shfl_xor(base, off, 64);
+                }
+                st0 = base + incl - c;
             } else {
                 st0 = m - c;
             }
-            if (t < P || t == 64) {
+            if (t < P || t == PART_MAXP) {
                 start[q] = st0;
                 if (c) {
                     const uint32_t room = PART_BLOCK - fill[q];          // 0 when no block is open
@@ -551,7 +557,7 @@ __global__ void __launch_bounds__(1024) k_hist_segments(const uint32_t *__restri
 bool sgc_part_supported(const sgc_table_view &lib, bool rec16) {
     if (rec16 || lib.gid_bits == 0) return false;
     if (lib.log2_slice > SGC_LDS_LOG2_SLICE || lib.log2_slice < 1) return false;
-    return (lib.log2_slots - lib.log2_slice) <= 6;      // <= PART_MAXP partitions
+    return (lib.log2_slots - lib.log2_slice) <= 7;      // <= PART_MAXP partitions
 }
 
 void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_part_geometry *g) {

@@ -82,6 +82,32 @@ def test_synthetic_workload_vs_oracle_2m(env, exact):
     wl.close()
 
 
+@pytest.mark.parametrize("variant", [4, 3])
+def test_large_library_128_slices(env, variant):
+    """150k guides need 128 library slices (64 hold ~105k): still the partitioned path, still the oracle's table."""
+    torch, S, synth, workload = env
+    n, ng = 1_500_000, 150_000
+    wl = workload.DeviceWorkload(n, ng, 20, one_mismatch=True, gen_chunk=700_000)
+    info = wl.dl.info()
+    assert info.lib_slots == 1 << 19 and info.core_partitions >= 256
+    wl.dl.set_option("variant", variant)
+    wl.step()
+    counts, total, matched = wl.result()
+    lib_text = synth.library_fasta(wl.lib_seqs)
+    lib = O.Library(lib_text)
+    ctr = O.Counter(lib, O.Permuter(lib), False, 30, 20, True)
+    for first in range(0, n, 500_000):
+        ctr.feed_text(synth.fastq_host(wl.lib_seqs, first, 500_000))
+    assert (counts.tolist(), total, matched) == (ctr.table(), ctr.total_reads(), ctr.matched_reads())
+    # the partitioned kernels ran (the generic fallback has no partition stage)
+    wl.dl.timing(True); wl.dl.timing(reset=True)
+    wl.step()
+    torch.cuda.synchronize()
+    assert wl.dl.timing(reset=True).part_ms > 0
+    wl.dl.timing(False)
+    wl.close()
+
+
 @pytest.mark.parametrize("L,reverse,recursion", [(20, False, True), (20, True, False), (27, False, True)])
 def test_fastq_ingest_on_device(env, L, reverse, recursion):
     """sgc_sample_push_fastq: record boundaries + packing on the GPU from raw FASTQ text == the oracle fed the
