@@ -44,7 +44,7 @@
 #define CP_SEG 1024u             // extents scanned per segment
 #define CP_MAXP (1u << SGC_CORE_MAX_LOG2_P)
 #define CP_DROP 0xFFFFu
-#define CP_CUR_STRIDE 32u         // one 128-byte line per partition cursor
+#define CP_CUR_STRIDE 8u          // partition cursors 32 bytes apart
 #define KC_THREADS 1024u
 #define KC_CHUNK 4096u           // records per unit of resolver work
 #define KC_GRID 512u
@@ -164,7 +164,7 @@ __device__ __forceinline__ void starts_from_totals(const uint32_t *__restrict__ 
 __global__ void __launch_bounds__(CP_THREADS) k_cp_scatter(cp_args a, const uint32_t *__restrict__ tot,
                                                            uint32_t *__restrict__ cursor, uint64_t *__restrict__ out) {
     __shared__ uint64_t stage[CP_TILE];
-    __shared__ uint8_t stage_p[CP_TILE];
+    __shared__ uint16_t stage_p[CP_TILE];
     __shared__ uint32_t cnt[CP_MAXP], start[CP_MAXP], cur[CP_MAXP], ps[CP_MAXP + 1];
     __shared__ uint32_t off_[CP_SEG], wsum[17];
     __shared__ __attribute__((aligned(8))) uint16_t map[CP_TILE];
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(CP_THREADS) k_cp_scatter(cp_args a, const uint
                 if (pr[k] != 0xFFFFFFFFu) {
                     const uint32_t at = start[pr[k] >> 16] + (pr[k] & 0xFFFFu);
                     stage[at] = rec[k];
-                    stage_p[at] = (uint8_t)(pr[k] >> 16);
+                    stage_p[at] = (uint16_t)(pr[k] >> 16);
                 }
             }
             if (t < P) cur[t] = ps[t] + got - st0;          // stage position j of partition p goes to cur[p] + j

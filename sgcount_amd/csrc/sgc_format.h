@@ -106,7 +106,7 @@ SGC_HD uint64_t sgc_bloom_mask(uint64_t h2) { return (1ull << (h2 & 63)) | (1ull
 #define SGC_CORE_LOG2_S 12u                                  // buckets per partition (log2)
 #define SGC_CORE_EMAX 2048u                                  // entry capacity of a partition
 #define SGC_CORE_STARTS ((1u << SGC_CORE_LOG2_S) + 2u)       // u16 per partition in starts[] (NB + 1, padded)
-#define SGC_CORE_MAX_LOG2_P 8u
+#define SGC_CORE_MAX_LOG2_P 9u                              // 512 partitions x 2048 entries: ~340k guides
 struct sgc_core_view {
     const uint64_t *ents;
     const uint32_t *gids;

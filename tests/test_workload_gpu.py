@@ -82,14 +82,15 @@ def test_synthetic_workload_vs_oracle_2m(env, exact):
     wl.close()
 
 
-@pytest.mark.parametrize("variant", [4, 3])
-def test_large_library_128_slices(env, variant):
-    """150k guides need 128 library slices (64 hold ~105k): still the partitioned path, still the oracle's table."""
+@pytest.mark.parametrize("variant,ng", [(4, 150_000), (3, 150_000), (4, 200_000)])
+def test_large_library_128_slices(env, variant, ng):
+    """150k-200k guides need 128 library slices (64 hold ~105k) and, from ~170k, 512 core partitions: still the
+    partitioned path with the in-LDS resolver, still the oracle's table."""
     torch, S, synth, workload = env
-    n, ng = 1_500_000, 150_000
+    n = 1_500_000
     wl = workload.DeviceWorkload(n, ng, 20, one_mismatch=True, gen_chunk=700_000)
     info = wl.dl.info()
-    assert info.lib_slots == 1 << 19 and info.core_partitions >= 256
+    assert info.lib_slots == 1 << 19 and info.core_partitions == (256 if ng == 150_000 else 512)
     wl.dl.set_option("variant", variant)
     wl.step()
     counts, total, matched = wl.result()
