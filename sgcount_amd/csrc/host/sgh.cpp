@@ -499,24 +499,28 @@ void count(const CountOptions &opt) {
                         "of your reference sequences (i.e. extracting the variable region of the sgRNA or reducing the length of "
                         "the adapters.)");
     }
-    // device tables: Library + (unless exact) Permuter, count.rs:103-107 — one context per visible GPU
+    // device tables: Library + (unless exact) Permuter, count.rs:103-107.  One context per worker thread (its own
+    // stream, scratch and table copy — ~0.15 GB at 100k guides), dealt round-robin over the visible GPUs: with -t N
+    // the samples of one GPU overlap too (one sample's inflate and parse run beside another's kernels), which is
+    // what the reference's rayon pool over samples gives on CPU cores.
     int n_dev = sgc_device_count();
     if (n_dev < 1) n_dev = 1;                                     // sgc_init below reports the missing device
     if (const char *v = getenv("SGCOUNT_DEVICES")) n_dev = std::max(1, std::min(n_dev, atoi(v)));
-    n_dev = (int)std::min<size_t>((size_t)n_dev, opt.input_paths.size());
+    const size_t n_workers = std::max<size_t>(1, std::min(opt.threads, opt.input_paths.size()));
+    const size_t n_ctx = std::min(opt.input_paths.size(), std::max<size_t>((size_t)n_dev, n_workers));
     std::string flat;
     flat.reserve(library.seqs.size() * library.size);
     for (const auto &s : library.seqs) flat += s;
     std::vector<sgc_ctx *> ctxs;
     struct CtxGuard { std::vector<sgc_ctx *> &v; ~CtxGuard() { for (auto c : v) sgc_free(c); } } cg{ctxs};
-    for (int d = 0; d < n_dev; d++) {
+    for (size_t k = 0; k < n_ctx; k++) {
         sgc_ctx *c = nullptr;
-        sgc_check(sgc_init(d, &c), "sgc_init");
+        sgc_check(sgc_init((int)(k % (size_t)n_dev), &c), "sgc_init");
         ctxs.push_back(c);
-        if (!opt.quiet && !opt.exact && d == 0) fprintf(stderr, "Generating Mismatch Library\n");
+        if (!opt.quiet && !opt.exact && k == 0) fprintf(stderr, "Generating Mismatch Library\n");
         sgc_check(sgc_set_library(c, (const uint8_t *)flat.data(), (uint32_t)library.seqs.size(), (uint32_t)library.size,
                                   !opt.exact), "sgc_set_library");
-        if (!opt.quiet && !opt.exact && d == 0) fprintf(stderr, "Finished Mismatch Library\n");
+        if (!opt.quiet && !opt.exact && k == 0) fprintf(stderr, "Finished Mismatch Library\n");
     }
     // samples in parallel (count.rs:117-136: rayon over samples, pool size -t), results in input order
     const size_t n = opt.input_paths.size();
@@ -525,14 +529,15 @@ void count(const CountOptions &opt) {
     std::vector<int> kinds(n, 0);
     std::atomic<size_t> next{0};
     std::vector<std::mutex> dev_mu(ctxs.size());
-    auto worker = [&]() {
+    auto worker = [&](size_t w) {
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= n) return;
-            const size_t d = i % ctxs.size();
+            // a worker keeps its own context; with fewer workers than contexts (GPUs) the samples are dealt over all of them
+            const size_t d = n_workers >= ctxs.size() ? w % ctxs.size() : i % ctxs.size();
             try {
                 if (!opt.quiet) fprintf(stderr, "Processing: %s\n", opt.sample_names[i].c_str());
-                std::lock_guard<std::mutex> lk(dev_mu[d]);      // one sample at a time per device context
+                std::lock_guard<std::mutex> lk(dev_mu[d]);      // one sample at a time per context
                 results[i] = count_sample(ctxs[d], opt.input_paths[i], opt.offsets[i], library, opt);
                 if (!opt.quiet)                                                           // count.rs:34-43
                     fprintf(stderr, "Finished: %s; Fraction mapped: %.3f [%llu / %llu]\n", opt.sample_names[i].c_str(),
@@ -544,8 +549,8 @@ void count(const CountOptions &opt) {
     };
     const size_t n_threads = std::max<size_t>(1, std::min(opt.threads, n));
     std::vector<std::thread> pool;
-    for (size_t t = 1; t < n_threads; t++) pool.emplace_back(worker);
-    worker();
+    for (size_t t = 1; t < n_threads; t++) pool.emplace_back(worker, t);
+    worker(0);
     for (auto &t : pool) t.join();
     for (size_t i = 0; i < n; i++) {                            // first failing sample aborts the run (count.rs:136-140)
         if (kinds[i] == 2) throw Panic(errors[i]);

@@ -51,6 +51,23 @@ def main():
         outs[label] = open(out).read()
         print("%-34s %.2f s  -> %.1f M reads/s end to end (process start to table, incl. table build)" % (
             label, best, args.reads / best / 1e6), flush=True)
+    # several .gz samples on one GPU: -t N gives every worker its own context, so inflate/parse of one sample overlaps
+    # the others' (the reference's rayon pool over samples)
+    k = 8
+    links = []
+    for i in range(k):
+        ln = os.path.join(args.dir, "s%d.fastq.gz" % i)
+        if os.path.lexists(ln):
+            os.remove(ln)
+        os.symlink(gz, ln)
+        links.append(ln)
+    for t in (1, k):
+        out = os.path.join(args.dir, "out_multi.tsv")
+        t0 = time.time()
+        subprocess.check_call([cli, "-l", lib_path, "-i"] + links + ["-a", "30", "-q", "-o", out, "-t", str(t)])
+        dt = time.time() - t0
+        print("%d x .gz samples, -t %-2d               %.2f s  -> %.1f M reads/s end to end" % (k, t, dt, k * args.reads / dt / 1e6),
+              flush=True)
     assert outs["plain, GPU-parsed FASTQ"] == outs["plain, host-parsed + GPU pack"] == outs["plain, host-parsed + host pack"] \
         == outs[".gz,   GPU-parsed FASTQ"]
 
