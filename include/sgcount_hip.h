@@ -160,7 +160,10 @@ void sgc_sample_free(sgc_sample *);
 void *sgc_alloc_pinned(size_t bytes);
 void sgc_free_pinned(void *p);
 
-/* Tuning knobs ("variant": count-kernel variant). */
+/* Tuning knobs (all results-preserving): "variant" (count path variant 0..4; default 4), "max_chunk"
+ * (records per internal pass), "k1_wgs" (workgroups of the partition kernel), "per_lane" (variant 2).  "dbg" sets
+ * timing-only ablation flags of the kernels — results are WRONG while it is non-zero, so it is refused unless
+ * SGC_ALLOW_DBG=1 is in the environment (tools/tune.py sets it). */
 int sgc_set_option(sgc_ctx *, const char *key, int64_t value);
 
 /* ---- diagnostics -------------------------------------------------------------------------------- */

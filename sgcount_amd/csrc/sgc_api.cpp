@@ -337,7 +337,11 @@ void sgc_free_pinned(void *p) { if (p) hipHostFree(p); }
 int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
     if (!c || !key) return fail(SGC_E_ARG, "sgc_set_option: NULL argument");
     if (!strcmp(key, "variant")) { c->variant = (int)value; return SGC_OK; }
-    if (!strcmp(key, "dbg")) { c->dbg = (uint32_t)value; return SGC_OK; }
+    if (!strcmp(key, "dbg")) {
+        // timing-only ablation flags of the kernels (results are WRONG when non-zero): profiling tools opt in
+        if (value && !getenv("SGC_ALLOW_DBG")) return fail(SGC_E_ARG, "sgc_set_option: dbg flags need SGC_ALLOW_DBG=1 in the environment");
+        c->dbg = (uint32_t)value; return SGC_OK;
+    }
     if (!strcmp(key, "k1_wgs")) { c->k1_wgs = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 65536)); return SGC_OK; }
     if (!strcmp(key, "max_chunk")) {
         if (value < 1 || value > (int64_t)0xF0000000ll) return fail(SGC_E_ARG, "max_chunk out of range");

@@ -13,6 +13,7 @@ import statistics
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("SGC_ALLOW_DBG", "1")      # this tool may set the kernels' timing-only ablation flags
 
 
 def main():
