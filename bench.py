@@ -2,23 +2,37 @@
 """bench.py — headline benchmark of the MI355X-native sgRNA count path.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A *step* is one pass of the hot path (per-read offset scan, library lookup, single-mismatch probe,
-count — reference src/counter.rs:96-236) over one whole sample of packed reads already resident in
-HBM, ending with the u64 count vector + totals exported on the device (one row per step).  For N > 1 every
-rank counts its own samples (seed + rank; weak scaling, no data-path collective): a step is one sample, and
-the rows of all K samples of all ranks are exchanged with ONE RCCL all-gather at the end of the batch, inside
-the timed region (fewer, larger collectives: K x 0.8 MB per rank).  Prints ONE JSON line (rank 0).
+N > 1 works both ways: under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (the
+driver's launch line: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment) and invoked directly —
+`python bench.py --gpus N` then starts N fresh child processes itself, one per GPU, BEFORE anything in this process
+has touched the GPU, waits for them and exits with their status.
 
-Workload (BASELINE.json): 100k-guide synthetic library, 100M x 150 bp synthetic reads, guide at
-offset 30 (-a 30), position recursion on; default `--workload 1mm` = configs[2] (the reference's
-default mode, exact + one mismatch — the configuration the north-star target is quoted on);
-`--workload exact` = configs[1] (-x).
+A *step* is one pass of the hot path (per-read offset scan, library lookup, single-mismatch probe, count — reference
+src/counter.rs:96-236) over one whole sample of packed reads already resident in HBM, ending with the u64 count
+vector + totals exported on the device (one row per step).  For N > 1 every rank counts its own samples (seed + rank;
+weak scaling, no data-path collective): a step is one sample, and the rows of all K samples of all ranks are exchanged
+with ONE RCCL all-gather at the end of the batch, inside the timed region (fewer, larger collectives: K x 0.8 MB per
+rank); the cost of that exchange is also measured on its own (`exchange`).  Prints ONE JSON line (rank 0).
+
+Workload (BASELINE.json): 100k-guide synthetic library, 100M x 150 bp synthetic reads, guide at offset 30 (-a 30),
+position recursion on; default `--workload 1mm` = configs[2] (the reference's default mode, exact + one mismatch — the
+configuration the north-star target is quoted on); `--workload exact` = configs[1] (-x).
+
+Besides the headline `value` (records resident in HBM), the line carries
+  roofline      the count pipeline against the HBM roofline, on both byte accountings (18 B/read with the
+                permute-table sector, and the 8 B/read the shipped path actually needs)
+  cpu_baseline  the CPU port (oracle/, 1 thread like the reference within a sample) on a bounded prefix, plus an
+                N-thread courtesy line and the probe for a reference binary
+  e2e           end to end: synthetic FASTQ *text* of the same sample in the page cache -> `sgcount-hip` -> count
+                table, plain and .gz, with the stages timed, next to the CPU port's end-to-end rate (N = 1 only)
 """
 import argparse
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,11 +41,65 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 ALGO_BYTES = {"exact": 8.0, "1mm": 18.0}   # algorithmic bytes per read
+NEEDED_BYTES = 8.0              # what the shipped path needs per read: one packed record (variant 4 reads no permute sector)
+FASTQ_BYTES_PER_READ = 316.0    # text of one synthetic record
 
 
-def cpu_baseline(lib_seqs, n_guides, L, offset, exact, recursion, seed, mode, budget_s, gpu_prefix_counts=None):
-    """Times the CPU oracle (a port of the reference's algorithm, 1 thread like the reference within a
-    sample) on a bounded prefix of the same workload, FASTQ text in → counts out."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=100_000_000, help="reads per sample (per GPU)")
+    ap.add_argument("--guides", type=int, default=100_000)
+    ap.add_argument("--workload", choices=["1mm", "exact"], default="1mm")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-oracle budget; 0 disables the baseline")
+    ap.add_argument("--variant", type=int, default=None, help="count-kernel variant (tuning)")
+    ap.add_argument("--e2e-reads", type=int, default=100_000_000, help="reads of the end-to-end FASTQ leg; 0 disables it")
+    ap.add_argument("--e2e-gz-reads", type=int, default=10_000_000, help="reads of the .gz end-to-end leg; 0 disables it")
+    ap.add_argument("--e2e-dir", default=None, help="where the FASTQ text is written (default: /dev/shm or /tmp)")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# N > 1 invoked directly: fresh child processes, one per rank, before this process touches the GPU
+# ---------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SGC_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in procs:            # one rank failed: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for q in procs:
+            q.kill()
+    sys.exit(rc)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# CPU baseline (bench.py's cpu_baseline leg is one of the three places that may load oracle/)
+# ---------------------------------------------------------------------------------------------------------
+def cpu_baseline(lib_seqs, L, offset, exact, recursion, seed, mode, budget_s):
+    """Times the CPU oracle (a port of the reference's algorithm, 1 thread like the reference within a sample) on a
+    bounded prefix of the same workload, FASTQ text in -> counts out; then the same port on N threads over disjoint
+    chunks as a courtesy "best CPU" line (NOT how the reference runs one sample)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
     from sgcount_amd import synth
@@ -48,23 +116,231 @@ def cpu_baseline(lib_seqs, n_guides, L, offset, exact, recursion, seed, mode, bu
         ctr.feed_text(text)
         spent += time.perf_counter() - t
         done += chunk
-    return {"value": done / spent, "unit": "reads/s", "cores": 1, "kind": "port",
-            "sample": "first %d reads of the same synthetic sample as FASTQ text (%.1f s of CPU; one-time "
+    base = {"value": done / spent, "unit": "reads/s", "cores": 1, "kind": "port",
+            "sample": "first %d reads of the same synthetic sample as FASTQ text in memory (%.1f s of CPU; one-time "
                       "library%s setup %.1f s excluded)" % (done, spent, "" if exact else "+permuter", setup_s),
-            "host_cpus": os.cpu_count()}, ctr, done
+            "setup_s": setup_s, "host_cpus": os.cpu_count(),
+            # probe for the real thing — expected absent (no Rust toolchain, no crates mirror)
+            "reference_binary": shutil.which("sgcount"), "cargo": shutil.which("cargo")}
+    # courtesy line: the same port on N threads (ctypes releases the GIL), every thread its own Counter over its own chunks
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        threads = max(1, min(16, (os.cpu_count() or 1)))
+        per_thread = 2
+        texts = [[synth.fastq_host(lib_seqs, (t * per_thread + k) * chunk, chunk, seed, mode) for k in range(per_thread)]
+                 for t in range(threads)]
+        ctrs = [O.Counter(lib, perm, False, offset, L, recursion) for _ in range(threads)]
+
+        def work(t):
+            for x in texts[t]:
+                ctrs[t].feed_text(x)
+        t = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(work, range(threads)))
+        dt = time.perf_counter() - t
+        base["n_thread_courtesy"] = {"value": threads * per_thread * chunk / dt, "unit": "reads/s", "cores": threads,
+                                     "note": "same port, reads dealt to N threads with private counters — not how the "
+                                             "reference runs a sample (one rayon task per sample, src/count.rs:117)"}
+    except Exception as e:                      # the courtesy line must never break the bench
+        base["n_thread_courtesy"] = {"error": repr(e)}
+    return base, ctr, done
+
+
+# ---------------------------------------------------------------------------------------------------------
+# end to end: FASTQ text in the page cache -> sgcount-hip -> table
+# ---------------------------------------------------------------------------------------------------------
+def _free_bytes(path):
+    try:
+        st = os.statvfs(path)
+        return st.f_bavail * st.f_frsize
+    except OSError:
+        return 0
+
+
+def _mem_available():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return 0
+
+
+def _run_cli(cli, argv, stats=None):
+    t0 = time.perf_counter()
+    p = subprocess.run([cli] + argv + (["--stats-json", stats] if stats else []), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    dt = time.perf_counter() - t0
+    if p.returncode != 0:
+        raise RuntimeError("sgcount-hip failed (%d): %s" % (p.returncode, p.stderr.decode()[-400:]))
+    return dt, (json.load(open(stats)) if stats else None)
+
+
+def _table_counts(path, n_guides):
+    import numpy as np
+    counts = np.zeros(n_guides, dtype=np.uint64)
+    with open(path, "rb") as f:
+        next(f)
+        for line in f:
+            g, c = line.split(b"\t")
+            counts[int(g[2:])] = int(c)
+    return counts
+
+
+def e2e_block(wl, args, exact, cpu):
+    """Synthetic FASTQ text of the bench sample -> sgcount-hip (process start to finished table)."""
+    import numpy as np
+    import torch
+    from sgcount_amd import hostlib, synth
+    out = {}
+    n = min(args.e2e_reads, args.reads)
+    need = n * FASTQ_BYTES_PER_READ * 1.02
+    cands = [args.e2e_dir] if args.e2e_dir else ["/dev/shm", "/tmp"]
+    avail = _mem_available()
+    where = None
+    for c in cands:
+        if c and os.path.isdir(c) and _free_bytes(c) > need * 1.05 and (avail == 0 or avail > need * 1.5):
+            where = c
+            break
+    if where is None:      # scale the sample down to what fits
+        best = max(cands, key=lambda c: _free_bytes(c) if c and os.path.isdir(c) else 0)
+        room = min(_free_bytes(best), avail / 1.5 if avail else 1e18)
+        n = int(min(n, room / (FASTQ_BYTES_PER_READ * 1.1)) // 1_000_000 * 1_000_000)
+        where = best
+        if n < 1_000_000:
+            return {"skipped": "no room for FASTQ text under %s" % cands}
+    d = os.path.join(where, "sgc_e2e_%d" % os.getpid())
+    os.makedirs(d, exist_ok=True)
+    try:
+        lib_path, fq, table = os.path.join(d, "library.fa"), os.path.join(d, "reads.fastq"), os.path.join(d, "table.tsv")
+        open(lib_path, "wb").write(synth.library_fasta(wl.lib_seqs))
+        t0 = time.perf_counter()
+        chunk = 2_000_000
+        pinned = None
+        with open(fq, "wb", buffering=0) as f:
+            for first in range(0, n, chunk):
+                m = min(chunk, n - first)
+                text, _ = synth.fastq_device(wl.lib_dev, first, m, wl.reads_seed, wl.mode)
+                if pinned is None or pinned.numel() < text.numel():
+                    pinned = torch.empty(int(text.numel() * 1.05), dtype=torch.uint8, pin_memory=True)
+                pinned[: text.numel()].copy_(text)
+                torch.cuda.synchronize()
+                f.write(memoryview(pinned.numpy())[: text.numel()])
+                del text
+        del pinned
+        size = os.path.getsize(fq)
+        out["fastq"] = {"reads": n, "bytes": size, "dir": where, "write_s": time.perf_counter() - t0}
+        cli = hostlib.cli_path()
+        base = ["-l", lib_path, "-a", "30", "-q", "-o", table] + (["-x"] if exact else [])
+        # plain text: two untimed-stats runs (best of), then one with the stage timers on
+        walls = [_run_cli(cli, base + ["-i", fq])[0] for _ in range(2)]
+        got = _table_counts(table, args.guides)
+        wl.step(0, n)
+        want, total, matched = wl.result()
+        parity = bool(np.array_equal(got, want))
+        _, stats = _run_cli(cli, base + ["-i", fq], stats=os.path.join(d, "stats.json"))
+        smp = stats["samples"][0]
+        wall = min(walls)
+        out["plain"] = {
+            "wall_s": wall, "reads_per_s": n / wall, "text_GBps": size / wall / 1e9, "wall_s_all_runs": walls,
+            "table_equals_resident_pass": parity,
+            "stages": {"library_load_s": stats["library_load_s"], "table_build_s": stats["table_build_s"],
+                       "sample_s": smp["wall_s"], "table_write_s": stats["table_write_s"],
+                       "file_read_busy_s_sum_over_threads": smp["read_busy_s"], "reader_threads": smp["reader_threads"],
+                       "host_waited_for_text_s": smp["wait_for_text_s"], "host_waited_for_upload_s": smp["wait_for_upload_s"],
+                       "host_in_push_calls_s": smp["push_s"], "drain_s": smp["finish_s"],
+                       "h2d_s": smp["h2d_ms"] / 1e3, "ingest_kernels_s": smp["ingest_kernels_ms"] / 1e3,
+                       "count_kernels_s": smp["count_kernels_ms"] / 1e3,
+                       "note": "stage timers from a separate run with --stats-json (HIP events on); uploads, ingest and "
+                               "count kernels of consecutive parts overlap, so the stages do not add up to sample_s"},
+            "ingest_text_GBps_vs_hbm": {"achieved": size / max(smp["ingest_kernels_ms"], 1e-9) / 1e6, "peak": HBM_PEAK_GBPS,
+                                         "note": "FASTQ text bytes / Σ(k_fastq_count + k_scan_tiles + k_fastq_pack) time"},
+        }
+        if cpu:
+            rate, setup = cpu["value"], cpu["setup_s"]
+            out["cpu_port"] = {"reads_per_s_setup_excluded": rate, "reads_per_s_setup_included": n / (n / rate + setup),
+                               "setup_s": setup, "cores": 1,
+                               "note": "the oracle's measured FASTQ-text rate (cpu_baseline) projected to the e2e sample size"}
+            out["speedup_plain"] = {"vs_cpu_setup_excluded": out["plain"]["reads_per_s"] / rate,
+                                    "vs_cpu_setup_included": out["plain"]["reads_per_s"] / out["cpu_port"]["reads_per_s_setup_included"]}
+        # .gz: one deflate stream is sequential — the run is bound by a single inflating core, whatever the GPU does
+        ngz = min(args.e2e_gz_reads, n)
+        if ngz > 0:
+            t0 = time.perf_counter()
+            gz = os.path.join(d, "reads.fastq.gz")
+            # the first ngz reads as their own text file, compressed as 16 gzip members in parallel (zlib reads
+            # concatenated members as one stream)
+            src = fq
+            if ngz < n:
+                src = os.path.join(d, "head.fastq")
+                with open(src, "wb", buffering=0) as f:
+                    for first in range(0, ngz, chunk):
+                        m = min(chunk, ngz - first)
+                        text, _ = synth.fastq_device(wl.lib_dev, first, m, wl.reads_seed, wl.mode)
+                        f.write(memoryview(text.cpu().numpy()))
+                        del text
+            gz_bytes = os.path.getsize(src)
+            parts = 16
+            per = (gz_bytes + parts - 1) // parts
+            procs = []
+            for k in range(parts):
+                lo, hi = k * per, min(gz_bytes, (k + 1) * per)
+                if lo >= hi:
+                    break
+                cmd = "tail -c +%d %s | head -c %d | gzip -1 > %s.%02d" % (lo + 1, src, hi - lo, gz, k)
+                procs.append(subprocess.Popen(["bash", "-c", cmd]))
+            for p in procs:
+                if p.wait() != 0:
+                    raise RuntimeError("gzip failed")
+            with open(gz, "wb") as o:
+                for k in range(len(procs)):
+                    with open("%s.%02d" % (gz, k), "rb") as part:
+                        shutil.copyfileobj(part, o, 1 << 24)
+                    os.remove("%s.%02d" % (gz, k))
+            prep = time.perf_counter() - t0
+            wall_gz, stats = _run_cli(cli, base + ["-i", gz], stats=os.path.join(d, "stats_gz.json"))
+            got = _table_counts(table, args.guides)
+            wl.step(0, ngz)
+            want_gz, total_gz, _ = wl.result()
+            smp = stats["samples"][0]
+            # one-thread inflate rate of the same file (zlib, like the reference's flate2 on its single sample thread)
+            import zlib
+            t0 = time.perf_counter()
+            dec, inflated = zlib.decompressobj(31), 0
+            with open(gz, "rb") as f:
+                while True:
+                    b = f.read(1 << 22)
+                    if not b:
+                        break
+                    while b:
+                        inflated += len(dec.decompress(b))
+                        b = dec.unused_data
+                        if dec.eof:
+                            dec = zlib.decompressobj(31)
+                        else:
+                            break
+            inflate_s = time.perf_counter() - t0
+            out["gz"] = {"reads": int(smp["reads"]), "gz_bytes": os.path.getsize(gz), "wall_s": wall_gz,
+                         "reads_per_s": smp["reads"] / wall_gz, "table_equals_resident_pass": bool(np.array_equal(got, want_gz)) and
+                         int(smp["reads"]) == total_gz, "sample_s": smp["wall_s"], "inflate_busy_s": smp["read_busy_s"],
+                         "zlib_inflate_alone_s": inflate_s, "prepare_s": prep,
+                         "note": "single-stream inflate bound: one core inflates at ~%.2f GB/s of text, the GPU side idles"
+                                 % (inflated / inflate_s / 1e9)}
+            if cpu:
+                r = smp["reads"]
+                cpu_gz = r / (inflate_s + r / cpu["value"])
+                out["gz"]["cpu_port_reads_per_s"] = cpu_gz
+                out["gz"]["speedup_vs_cpu"] = out["gz"]["reads_per_s"] / cpu_gz
+                out["gz"]["cpu_note"] = "CPU port composed as inflate (measured here, zlib) + count (cpu_baseline rate) on one thread"
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reads", type=int, default=100_000_000, help="reads per sample (per GPU)")
-    ap.add_argument("--guides", type=int, default=100_000)
-    ap.add_argument("--workload", choices=["1mm", "exact"], default="1mm")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-oracle budget; 0 disables the baseline")
-    ap.add_argument("--variant", type=int, default=None, help="count-kernel variant (tuning)")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                      # never returns
 
     import torch
     import torch.distributed as dist
@@ -76,8 +352,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     n_dev = torch.cuda.device_count()
     dev_index = local_rank % max(n_dev, 1)          # one rank per GPU on a full node; ranks share a card only in rehearsals
     torch.cuda.set_device(dev_index)
@@ -127,6 +402,7 @@ def main():
     elapsed = time.perf_counter() - t0
     tm = wl.dl.timing(reset=True)
     wl.dl.timing(False)
+    exch = None
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -134,6 +410,27 @@ def main():
         # every rank holds every sample row of the batch: rank r's step-0 row must be what rank r counted
         got = matrix.view(world, rows.shape[0], row_len)[rank, 0].to(rows.device)
         assert torch.equal(got, rows[0]), "exchanged count matrix does not hold this rank's row"
+        # the exchange on its own (outside the timed region): the whole batch of K rows, and a single sample row
+        one = torch.zeros((world, row_len), dtype=torch.int64, device=coll_dev)
+
+        def timed_exchange(fn, reps=5):
+            fence()
+            t = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            fence()
+            x = torch.tensor([(time.perf_counter() - t) / reps], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(x, op=dist.ReduceOp.MAX)
+            return float(x.item()) * 1e3
+        batch_ms = timed_exchange(exchange)
+        row_ms = timed_exchange(lambda: all_gather_rows((rows[0] if backend == "nccl" else rows[0].cpu()), one))
+        devs = [None] * world
+        dist.all_gather_object(devs, {"rank": rank, "device": dev_index, "name": torch.cuda.get_device_name(dev_index)})
+        exch = {"backend": backend, "ranks_seen": dist.get_world_size(), "rank_devices": devs,
+                "all_gather_batch_ms": batch_ms, "batch_rows_per_rank": rows.shape[0], "batch_bytes_per_rank": rows.numel() * 8,
+                "all_gather_one_sample_ms": row_ms, "sample_row_bytes": row_len * 8,
+                "note": "the timed region holds ONE all-gather per batch of K steps; all_gather_one_sample_ms is what a "
+                        "per-sample exchange would cost per step instead"}
 
     counts, total, matched = wl.result(rows[(args.steps - 1) % rows.shape[0]])
     assert total == args.reads and int(counts.sum()) == matched, "count-sum invariant violated"
@@ -150,7 +447,10 @@ def main():
                    "reads_per_gpu": args.reads, "guides": args.guides, "guide_len": L, "record_bytes": wl.dl.record_bytes,
                    "parallelism": "1 sample per GPU per step" + ("" if world == 1 else ", one RCCL all-gather of all sample rows per batch of K steps")},
         "matched_fraction": matched / total,
+        "launch": "self-launched children" if os.environ.get("SGC_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else "single process"),
     }
+    if exch:
+        out["exchange"] = exch
     if rank == 0:
         reads_timed = args.reads * args.steps
         # the count path is a short pipeline of kernels over the same reads; the roofline is
@@ -161,6 +461,7 @@ def main():
         dom_ms = sum(parts.values())
         bpr = ALGO_BYTES[args.workload]
         achieved = bpr * reads_timed / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else None
+        needed = NEEDED_BYTES * reads_timed / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else None
         # HBM bytes per pass from the rocprofv3 PMC passes committed under profiles/ (tools/pmc_traffic.py:
         # separate --pmc FETCH_SIZE / WRITE_SIZE runs of this command, gfx950 FETCH_SIZE correction calibrated
         # on k_partition's known byte count); only quoted for the configuration it was collected on
@@ -170,19 +471,22 @@ def main():
             try:
                 d = json.load(open(pmc)).get(args.workload)
                 traffic = d["hbm_bytes_per_step"]
-                traffic_note = "%.1f HBM B/read measured vs %.0f algorithmic" % (d["bytes_per_read"], ALGO_BYTES[args.workload])
+                traffic_note = "%.1f HBM B/read measured (%s) vs %.0f algorithmic" % (d["bytes_per_read"], d.get("collected", "profiles/"), ALGO_BYTES[args.workload])
             except Exception:
                 traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                            "traffic_note": traffic_note,
-                           "kernel": ("count pipeline (k_partition + k_count_slices + k_cp_count/k_cp_scatter + k_core, twice)" if not exact
+                           "kernel": ("count pipeline (k_partition + k_count_slices + core partition/resolve kernels)" if not exact
                                       else "count pipeline (k_partition + k_count_slices + k_generic + k_resolve_miss + k_hist_segments)"),
                            "algorithmic_bytes_per_read": bpr,
+                           # the strict accounting: the shipped path reads no permute-table sector, a read is one 8-byte record
+                           "needed_bytes_per_read": NEEDED_BYTES, "achieved_on_needed_bytes": needed,
+                           "frac_on_needed_bytes": (needed / HBM_PEAK_GBPS) if needed else None,
                            "kernel_ms_per_step": dom_ms / args.steps, "kernels": kernels}
+        base = None
         if world == 1 and args.cpu_seconds > 0:
-            base, ctr, m = cpu_baseline(wl.lib_seqs, args.guides, L, offset, exact, recursion, synth.READS_SEED, 0,
-                                        args.cpu_seconds)
+            base, ctr, m = cpu_baseline(wl.lib_seqs, L, offset, exact, recursion, synth.READS_SEED, 0, args.cpu_seconds)
             out["cpu_baseline"] = base
             # free parity check: the GPU path on the very same prefix must give the oracle's table
             wl.step(0, min(m, args.reads))
@@ -190,7 +494,13 @@ def main():
             if m <= args.reads:
                 ok = (g_counts.tolist() == ctr.table() and g_matched == ctr.matched_reads() and g_total == ctr.total_reads())
                 out["parity_vs_oracle_on_cpu_sample"] = "bit-exact" if ok else "MISMATCH"
-            out["speedup_vs_cpu_baseline"] = out["value"] / base["value"]
+            out["kernel_vs_cpu_note"] = ("value / cpu_baseline.value compares resident packed records on the GPU with FASTQ text on one "
+                                         "CPU thread: not a like-for-like ratio — see e2e for file-to-table against the same CPU port")
+        if world == 1 and args.e2e_reads > 0:
+            try:
+                out["e2e"] = e2e_block(wl, args, exact, base)
+            except Exception as e:              # the e2e leg must never cost the headline line
+                out["e2e"] = {"error": repr(e)[:500]}
         print(json.dumps(out), flush=True)
     wl.close()
     if world > 1:

@@ -40,6 +40,7 @@ extern "C" {
 #define SGC_E_DUPLICATE (-4)    /* duplicate library sequence — src/library.rs:91-96 panics */
 #define SGC_E_STATE (-5)        /* call order (no library set, sample finished, ...) */
 #define SGC_E_OOM (-6)
+#define SGC_E_FORMAT (-7)       /* malformed FASTQ text (a header line without '@', a separator without '+') — fxread panics */
 
 #define SGC_MEM_HOST 0          /* pointer is host memory (pinned or pageable) */
 #define SGC_MEM_DEVICE 1        /* pointer is device memory on the ctx's device */
@@ -58,6 +59,7 @@ typedef struct {
     double   pack_ms;        /* Σ duration of the on-device pack kernel(s) */
     double   part_ms;        /* Σ duration of the partition kernel (partitioned path) */
     double   miss_ms;        /* Σ duration of the miss-resolution kernel (partitioned path) */
+    double   h2d_ms;         /* Σ duration of the host-to-device copies of FASTQ text (upload stream) */
 } sgc_timing;
 
 typedef struct {
@@ -93,7 +95,7 @@ void *sgc_get_stream(sgc_ctx *);
  * in library-file order.  Builds the device tables once; they are read-only afterwards and shared by
  * every sample of the ctx.  SGC_E_DUPLICATE mirrors the duplicate-sequence panic; SGC_E_UNSUPPORTED
  * is returned for sequences with bytes outside ACGT or L > SGC_MAX_GUIDE_LEN (the caller must fail
- * loudly: there is no CPU fallback behind this ABI). */
+ * loudly: there is no CPU fallback behind this ABI).  On any error the ctx holds no library afterwards. */
 int sgc_set_library(sgc_ctx *, const uint8_t *seqs, uint32_t n, uint32_t L, int enable_1mm);
 int sgc_library_info(sgc_ctx *, sgc_lib_info *out);
 
@@ -133,8 +135,26 @@ int sgc_sample_push_packed(sgc_sample *, const void *records, uint64_t n, int wh
 int sgc_sample_push_reads(sgc_sample *, const uint8_t *seqs, const uint64_t *offsets, uint64_t n, int where);
 
 /* Same, from a chunk of FASTQ text holding whole 4-line records: the device finds the record
- * boundaries, packs and counts.  n_records_out may be NULL. */
+ * boundaries, packs and counts.  n_records_out may be NULL.  Waits for the device's line count (one stream
+ * synchronisation per call); a streaming host uses sgc_sample_push_fastq_part instead. */
 int sgc_sample_push_fastq(sgc_sample *, const uint8_t *text, uint64_t n_bytes, int where, uint64_t *n_records_out);
+
+/* Streaming form (what replaces the fxread iterator inside Counter::count, src/counter.rs:211-236, for FASTQ input):
+ * `text` is the next run of WHOLE LINES of the sample's FASTQ stream — it may begin and end anywhere in the 4-line
+ * cycle — first_line is the 0-based number of its first line within the stream and n_newlines the number of '\n' in
+ * it (the host counts them while it reads; UINT64_MAX = unknown: the call then waits for the device's count).  Only
+ * the very last part of a stream may end without a '\n'.  Fully asynchronous when n_newlines is given: host text is
+ * uploaded on a separate stream into alternating device buffers, so the upload of one part overlaps the ingest and
+ * count kernels of the part before; the host buffer may be reused once sgc_sample_wait_uploads says so.  A '\r'
+ * before a '\n' counts as part of the line terminator.  Lines 4k must start with '@' and lines 4k+2 with '+':
+ * violations (and a wrong n_newlines) surface as SGC_E_FORMAT from the next sgc_sample_sync / sgc_sample_finish.
+ * The caller checks at the end of the stream that the total number of lines is a multiple of 4. */
+int sgc_sample_push_fastq_part(sgc_sample *, const uint8_t *text, uint64_t n_bytes, int where, uint64_t first_line,
+                               uint64_t n_newlines, uint64_t *n_records_out);
+
+/* Blocks until at most max_pending of the most recent host-text uploads are still in flight: the host buffers of
+ * all earlier sgc_sample_push_fastq_part calls can then be overwritten. */
+int sgc_sample_wait_uploads(sgc_sample *, uint32_t max_pending);
 
 int sgc_sample_sync(sgc_sample *);
 
@@ -161,7 +181,9 @@ void *sgc_alloc_pinned(size_t bytes);
 void sgc_free_pinned(void *p);
 
 /* Tuning knobs (all results-preserving): "variant" (count path variant 0..4; default 4), "max_chunk"
- * (records per internal pass), "k1_wgs" (workgroups of the partition kernel), "per_lane" (variant 2).  "dbg" sets
+ * (records per internal pass), "k1_wgs" (workgroups of the partition kernel), "per_lane" (variant 2), "host_build" /
+ * "perm_bloom_bits" (how the next sgc_set_library builds the single-mismatch table and its filter).  No environment
+ * variable changes what the library computes or which kernels it runs.  "dbg" sets
  * timing-only ablation flags of the kernels — results are WRONG while it is non-zero, so it is refused unless
  * SGC_ALLOW_DBG=1 is in the environment (tools/tune.py sets it). */
 int sgc_set_option(sgc_ctx *, const char *key, int64_t value);

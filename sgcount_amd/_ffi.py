@@ -8,7 +8,7 @@ import os
 
 from . import build as _build
 
-OK, E_ARG, E_HIP, E_UNSUPPORTED, E_DUPLICATE, E_STATE, E_OOM = 0, -1, -2, -3, -4, -5, -6
+OK, E_ARG, E_HIP, E_UNSUPPORTED, E_DUPLICATE, E_STATE, E_OOM, E_FORMAT = 0, -1, -2, -3, -4, -5, -6, -7
 MEM_HOST, MEM_DEVICE = 0, 1
 
 
@@ -20,7 +20,7 @@ class SgcError(RuntimeError):
 
 class Timing(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("lookup_ms", C.c_double), ("hist_ms", C.c_double),
-                ("pack_ms", C.c_double), ("part_ms", C.c_double), ("miss_ms", C.c_double)]
+                ("pack_ms", C.c_double), ("part_ms", C.c_double), ("miss_ms", C.c_double), ("h2d_ms", C.c_double)]
 
 
 class LibInfo(C.Structure):
@@ -47,6 +47,8 @@ SYMBOLS = {
     "sgc_sample_push_packed": (_i, [_vp, _vp, _u64, _i]),
     "sgc_sample_push_reads": (_i, [_vp, _u8p, _vp, _u64, _i]),
     "sgc_sample_push_fastq": (_i, [_vp, _u8p, _u64, _i, C.POINTER(_u64)]),
+    "sgc_sample_push_fastq_part": (_i, [_vp, _u8p, _u64, _i, _u64, _u64, C.POINTER(_u64)]),
+    "sgc_sample_wait_uploads": (_i, [_vp, _u32]),
     "sgc_sample_sync": (_i, [_vp]),
     "sgc_sample_finish": (_i, [_vp, _vp, C.POINTER(_u64), C.POINTER(_u64)]),
     "sgc_sample_flush": (_i, [_vp]),

@@ -2,11 +2,16 @@
 // the GPU through the C ABI of include/sgcount_hip.h (count()).
 #include "sgh.hpp"
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -91,6 +96,8 @@ bool FastxReader::next(RecordView &r) {
         if (!get(2) || l[2] == 0 || s.buf[o[2]] != '+') throw Panic("malformed FASTQ record in " + s.path);
         if (!get(3)) throw Panic("truncated FASTQ record in " + s.path);
     }
+    // a '\r' before the '\n' is part of the line terminator (CRLF files; fxread's behaviour is unpinned)
+    for (int k = 0; k < 2; k++) if (l[k] && s.buf[o[k] + l[k] - 1] == '\r') l[k]--;
     r.id = s.buf.data() + o[0] + 1; r.id_len = l[0] - 1;
     r.seq = s.buf.data() + o[1]; r.seq_len = l[1];
     return true;
@@ -332,12 +339,19 @@ static void sgc_check(int rc, const char *what) {
     }
 }
 
-// FASTQ at speed (replaces fxread for the count loop): the host only inflates/reads text and cuts it at record
-// boundaries by counting newlines; record boundaries inside a chunk, window extraction and packing happen on
-// the GPU (sgc_sample_push_fastq).  Two pinned buffers alternate so that reading chunk k+1 overlaps counting k.
+// =====================================================================================================
+// FASTQ at speed (replaces fxread inside the count loop, src/count.rs:24 + src/counter.rs:211-236)
+//
+// The host never parses records.  It moves text from the page cache (or from zlib) into pinned buffers with several
+// threads, counts the newlines of every block while it is still cache-hot, cuts each slice at its last newline and
+// hands [carry | slice] to sgc_sample_push_fastq_part together with the line number it starts at.  Record boundaries,
+// marker validation, window extraction and packing happen on the GPU; uploads, ingest kernels and count kernels of
+// consecutive parts overlap (upload stream + alternating device buffers inside the library).
+// =====================================================================================================
+
 // Number of '\n' in [p, p + n): byte compares summed in 8-bit lanes (the compiler turns the inner loop into vector
 // compares; 255 iterations cannot overflow a lane), flushed to a wide sum.
-static size_t count_newlines(const uint8_t *p, size_t n) {
+size_t count_newlines(const uint8_t *p, size_t n) {
     size_t total = 0;
     while (n) {
         const size_t m = std::min<size_t>(n, 255 * 64);
@@ -352,101 +366,238 @@ static size_t count_newlines(const uint8_t *p, size_t n) {
     return total;
 }
 
-// Byte source of the text path: a plain file is read with read(2) straight into the caller's (pinned) buffer; a
-// gzip stream (magic 1f 8b) goes through zlib.
-struct TextSource {
-    FILE *fp = nullptr;
-    gzFile gz = nullptr;
-    explicit TextSource(const std::string &path) {
-        fp = fopen(path.c_str(), "rb");
-        if (!fp) throw Error("No such file or directory (os error 2): " + path);
-        unsigned char magic[2] = {0, 0};
-        const size_t got = fread(magic, 1, 2, fp);
-        if (got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
-            fclose(fp); fp = nullptr;
-            gz = gzopen(path.c_str(), "rb");
-            if (!gz) throw Error("No such file or directory (os error 2): " + path);
-            gzbuffer(gz, 1u << 20);
-        } else {
-            rewind(fp);
-            setvbuf(fp, nullptr, _IONBF, 0);             // unbuffered: fread becomes read(2) into our buffer
-        }
-    }
-    ~TextSource() { if (fp) fclose(fp); if (gz) gzclose(gz); }
-    // up to n bytes; 0 = end of stream
-    size_t read(uint8_t *dst, size_t n, const std::string &path) {
-        if (gz) {
-            const int got = gzread(gz, dst, (unsigned)std::min<size_t>(n, 1u << 30));
-            if (got < 0) throw Error("read error in " + path);
-            return (size_t)got;
-        }
-        const size_t got = fread(dst, 1, n, fp);
-        if (got == 0 && ferror(fp)) throw Error("read error in " + path);
-        return got;
-    }
-};
-
-// Where to cut a chunk of FASTQ text so that it holds whole 4-line records: count the newlines, then step back over
-// the (count mod 4) complete lines — and the unterminated one — that belong to the record the chunk ends inside.
-// The final chunk (eof) is taken whole; its last line may lack the newline.
-size_t fastq_chunk_cut(const uint8_t *buf, size_t have, bool eof, const std::string &path) {
-    const size_t lines = count_newlines(buf, have);
-    if (eof) {
-        const size_t tail_lines = lines + (have && buf[have - 1] != '\n' ? 1 : 0);
-        if (tail_lines % 4 != 0) throw Panic("truncated FASTQ record in " + path);
-        return have;
-    }
-    size_t back = lines & 3, end = have;
-    for (;;) {
-        const void *nl = end ? memrchr(buf, '\n', end) : nullptr;
-        if (!nl) { end = 0; break; }
-        end = (size_t)((const uint8_t *)nl - buf);           // index of that newline
-        if (back == 0) { end += 1; break; }
-        back--;
-    }
-    if (end == 0) throw Error("FASTQ record larger than the text chunk in " + path);
-    return end;
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-static bool count_fastq_text(sgc_sample *smp, const std::string &path, const CountOptions &opt) {
-    TextSource src(path);
-    const size_t cap = std::max<size_t>(opt.chunk_bytes, 1u << 16);
-    uint8_t *buf[2] = {(uint8_t *)sgc_alloc_pinned(cap), (uint8_t *)sgc_alloc_pinned(cap)};
-    struct BGuard { uint8_t **b; ~BGuard() { sgc_free_pinned(b[0]); sgc_free_pinned(b[1]); } } bg{buf};
-    if (!buf[0] || !buf[1]) throw Error("cannot allocate pinned host buffers");
-    size_t have = 0;                                     // bytes carried over (an incomplete record)
-    int cur = 0;
-    bool eof = false, first_chunk = true;
-    while (!eof || have) {
-        while (have < cap && !eof) {
-            const size_t got = src.read(buf[cur] + have, cap - have, path);
-            if (got == 0) eof = true;
-            have += got;
+TextFeeder::TextFeeder(const std::string &path_, size_t slice_bytes, size_t ring, size_t threads, void *(*alloc)(size_t),
+                       void (*release)(void *))
+    : path(path_), free_fn(release) {
+    fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw Error("No such file or directory (os error 2): " + path);
+    unsigned char magic[2] = {0, 0};
+    const ssize_t got = pread(fd, magic, 2, 0);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) { close(fd); throw Error("cannot stat " + path); }
+    file_size = (size_t)sb.st_size;
+    is_gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+    if (is_gz) {
+        gz = gzdopen(dup(fd), "rb");
+        if (!gz) { close(fd); throw Error("cannot open the gzip stream of " + path); }
+        gzbuffer(gz, 1u << 20);
+        threads = 1;
+        slice_bytes = std::min<size_t>(slice_bytes, 32u << 20);
+    } else {
+        // small inputs do not need the full-size ring
+        const size_t need = std::max<size_t>((file_size + 4095) & ~(size_t)4095, 1u << 16);
+        slice_bytes = std::min(slice_bytes, need);
+        n_slices_known = (file_size + slice_bytes - 1) / slice_bytes;
+        if (n_slices_known == 0) n_slices_known = 1;
+        first_byte = got >= 1 ? magic[0] : 0;
+    }
+    slice = std::max<size_t>(slice_bytes, 1u << 16);
+    n_threads = std::max<size_t>(1, threads);
+    ring_n = std::max<size_t>(2, ring);
+    bufs.assign(ring_n, nullptr);
+    for (size_t i = 0; i < ring_n; i++) {
+        bufs[i] = (uint8_t *)alloc(HEAD + slice);
+        if (!bufs[i]) { shutdown(); throw Error("cannot allocate pinned host buffers"); }
+    }
+    slots.resize(ring_n);
+    if (is_gz) {
+        // the first byte of the stream decides "FASTQ or not": inflate the first slice eagerly in the producer
+        workers.emplace_back([this] { run_gz(); });
+        // wait for slice 0 to learn the first byte
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this] { return (slots[0].ready && slots[0].index == 0) || failed; });
+        if (!failed) first_byte = slots[0].len ? bufs[0][HEAD] : 0;
+    } else {
+        for (size_t t = 0; t < n_threads; t++) workers.emplace_back([this] { run_plain(); });
+    }
+}
+
+void TextFeeder::shutdown() {
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        stop = true;
+    }
+    cv.notify_all();
+    for (auto &w : workers) if (w.joinable()) w.join();
+    workers.clear();
+    for (auto &b : bufs) if (b) { free_fn(b); b = nullptr; }
+    if (gz) { gzclose(gz); gz = nullptr; }
+    if (fd >= 0) { close(fd); fd = -1; }
+}
+
+TextFeeder::~TextFeeder() { shutdown(); }
+
+// plain files: jobs (slice k, sub-range j) are handed out in order; a job of slice k may start once the buffer of
+// slice k - ring has been released
+void TextFeeder::run_plain() {
+    try {
+        for (;;) {
+            size_t job;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                job = next_job++;
+                const size_t k = job / n_threads;
+                if (k >= n_slices_known) return;
+                cv.wait(lk, [&] { return stop || k < released + ring_n; });
+                if (stop) return;
+                Slot &sl = slots[k % ring_n];
+                if (sl.index != k) { sl.index = k; sl.ready = false; sl.pending = n_threads; sl.newlines = 0; sl.len = 0; sl.eof = false; }
+            }
+            const size_t k = job / n_threads, j = job % n_threads;
+            const size_t s0 = k * slice, s_len = std::min(slice, file_size - std::min(file_size, s0));
+            // sub-range j of the slice, cut at 4 KiB multiples
+            const size_t per = ((s_len + n_threads - 1) / n_threads + 4095) & ~(size_t)4095;
+            const size_t lo = std::min(s_len, j * per), hi = std::min(s_len, lo + per);
+            uint8_t *dst = bufs[k % ring_n] + HEAD;
+            const double t0 = now_s();
+            uint64_t nl = 0;
+            for (size_t off = lo; off < hi;) {
+                const size_t want = std::min<size_t>(hi - off, 1u << 20);
+                const ssize_t r = pread(fd, dst + off, want, (off_t)(s0 + off));
+                if (r < 0) throw Error("read error in " + path);
+                if (r == 0) throw Error("file shrank while reading: " + path);
+                nl += count_newlines(dst + off, (size_t)r);
+                off += (size_t)r;
+            }
+            const double dt = now_s() - t0;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                Slot &sl = slots[k % ring_n];
+                sl.newlines += nl;
+                busy_s += dt;
+                if (--sl.pending == 0) { sl.len = s_len; sl.eof = k + 1 == n_slices_known; sl.ready = true; }
+            }
+            cv.notify_all();
         }
-        if (first_chunk) {
-            if (!have || buf[cur][0] != '@') return false;    // not FASTQ: the caller uses the record reader
-            first_chunk = false;
+    } catch (const std::exception &e) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!failed) { failed = true; error = e.what(); }
+        cv.notify_all();
+    }
+}
+
+// gzip streams: one inflating producer (a deflate stream is sequential), slices filled in order
+void TextFeeder::run_gz() {
+    try {
+        for (size_t k = 0;; k++) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || k < released + ring_n; });
+                if (stop) return;
+                Slot &sl = slots[k % ring_n];
+                sl.index = k; sl.ready = false; sl.newlines = 0; sl.len = 0; sl.eof = false;
+            }
+            uint8_t *dst = bufs[k % ring_n] + HEAD;
+            const double t0 = now_s();
+            size_t have = 0; uint64_t nl = 0; bool eof = false;
+            while (have < slice) {
+                const int r = gzread(gz, dst + have, (unsigned)std::min<size_t>(slice - have, 1u << 20));
+                if (r < 0) throw Error("read error in " + path);
+                if (r == 0) { eof = true; break; }
+                nl += count_newlines(dst + have, (size_t)r);
+                have += (size_t)r;
+            }
+            const double dt = now_s() - t0;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                Slot &sl = slots[k % ring_n];
+                sl.len = have; sl.newlines = nl; sl.eof = eof; sl.ready = true;
+                busy_s += dt;
+            }
+            cv.notify_all();
+            if (eof) return;
         }
-        const size_t cut = fastq_chunk_cut(buf[cur], have, eof, path);
-        if (cut) {
-            sgc_check(sgc_sample_sync(smp), "sgc_sample_sync");          // the other buffer's count pass may still be running
-            sgc_check(sgc_sample_push_fastq(smp, buf[cur], cut, SGC_MEM_HOST, nullptr), "sgc_sample_push_fastq");
+    } catch (const std::exception &e) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!failed) { failed = true; error = e.what(); }
+        cv.notify_all();
+    }
+}
+
+bool TextFeeder::acquire(size_t k, uint8_t *&data, size_t &len, uint64_t &newlines, bool &eof) {
+    const double t0 = now_s();
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return failed || (slots[k % ring_n].index == k && slots[k % ring_n].ready); });
+    wait_s += now_s() - t0;
+    if (failed) throw Error(error);
+    const Slot &sl = slots[k % ring_n];
+    data = bufs[k % ring_n] + HEAD; len = sl.len; newlines = sl.newlines; eof = sl.eof;
+    return true;
+}
+
+void TextFeeder::release_below(size_t k) {
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (k > released) released = k;
+    }
+    cv.notify_all();
+}
+
+// Streams one FASTQ file through sgc_sample_push_fastq_part.  Returns false (nothing pushed) if the input is not
+// FASTQ (first byte not '@'): the caller then uses the record reader.
+static bool count_fastq_text(sgc_sample *smp, const std::string &path, const CountOptions &opt, SampleStats *st) {
+    TextFeeder feed(path, std::max<size_t>(opt.chunk_bytes, 1u << 16), 3, opt.io_threads, sgc_alloc_pinned, sgc_free_pinned);
+    if (feed.first_byte != '@') return false;
+    uint64_t first_line = 0;
+    size_t carry = 0;                                  // bytes of an unfinished line, already sitting in front of the slice
+    double t_push = 0, t_upwait = 0;
+    for (size_t k = 0;; k++) {
+        uint8_t *data; size_t len; uint64_t newlines; bool eof;
+        feed.acquire(k, data, len, newlines, eof);
+        uint8_t *part = data - carry;
+        size_t part_len = carry + len, tail = 0;
+        if (!eof) {
+            // cut at the last newline of the slice; what follows is carried in front of the next slice
+            const void *nl = len ? memrchr(data, '\n', len) : nullptr;
+            const size_t keep = nl ? (size_t)((const uint8_t *)nl - part) + 1 : 0;
+            tail = part_len - keep;
+            if (tail > TextFeeder::HEAD) throw Error("FASTQ line longer than " + std::to_string(TextFeeder::HEAD) + " bytes in " + path);
+            memcpy(feed.buffer_of(k + 1) + TextFeeder::HEAD - tail, part + keep, tail);
+            part_len = keep;
+        } else {
+            // trailing blank lines at the very end of the file are not records
+            while (part_len >= 2 && part[part_len - 1] == '\n' && part[part_len - 2] == '\n') { part_len--; newlines--; }
         }
-        const size_t rest = have - cut;
-        memcpy(buf[cur ^ 1], buf[cur] + cut, rest);
-        have = rest;
-        cur ^= 1;
-        if (eof && !have) break;
+        if (part_len) {
+            double t0 = now_s();
+            sgc_check(sgc_sample_push_fastq_part(smp, part, part_len, SGC_MEM_HOST, first_line, newlines, nullptr),
+                      "sgc_sample_push_fastq_part");
+            t_push += now_s() - t0;
+            first_line += newlines + (part[part_len - 1] != '\n' ? 1 : 0);
+            // the buffer of slice k - 1 may be refilled once its upload is through (this part's may still be in flight)
+            t0 = now_s();
+            sgc_check(sgc_sample_wait_uploads(smp, 1), "sgc_sample_wait_uploads");
+            t_upwait += now_s() - t0;
+            feed.release_below(k);
+        } else {
+            sgc_check(sgc_sample_wait_uploads(smp, 0), "sgc_sample_wait_uploads");
+            feed.release_below(k);
+        }
+        carry = tail;
+        if (eof) break;
+    }
+    if (first_line % 4 != 0) throw Panic("truncated FASTQ record in " + path);
+    if (st) {
+        st->text_bytes = feed.is_gz ? 0 : feed.file_size;
+        st->reader_threads = feed.n_threads;
+        st->read_busy_s = feed.busy_s; st->read_wait_s = feed.wait_s; st->push_s = t_push; st->upload_wait_s = t_upwait;
+        st->gz = feed.is_gz;
     }
     return true;
 }
 
 static SampleCounts count_sample(sgc_ctx *ctx, const std::string &path, const Offset &off, const Library &library,
-                                 const CountOptions &opt) {
+                                 const CountOptions &opt, SampleStats *st) {
+    const double t_begin = now_s();
     sgc_sample *smp = nullptr;
     sgc_check(sgc_sample_begin(ctx, &smp, off.reverse, (uint32_t)off.index, opt.position_recursion), "sgc_sample_begin");
     struct Guard { sgc_sample *s; ~Guard() { sgc_sample_free(s); } } guard{smp};
-    const bool parsed_on_device = opt.device_parse && opt.device_pack && count_fastq_text(smp, path, opt);
+    const bool parsed_on_device = opt.device_parse && opt.device_pack && count_fastq_text(smp, path, opt, st);
+    if (st) st->text_path = parsed_on_device;
     if (!parsed_on_device) {
     FastxReader reader(path);                                                         // count.rs:24
     const uint32_t L = (uint32_t)library.size;
@@ -478,13 +629,28 @@ static SampleCounts count_sample(sgc_ctx *ctx, const std::string &path, const Of
     }
     std::vector<uint64_t> counts(library.seqs.size());
     SampleCounts out;
-    sgc_check(sgc_sample_finish(smp, counts.data(), &out.total_reads, &out.matched_reads), "sgc_sample_finish");
+    const double t_fin = now_s();
+    const int frc = sgc_sample_finish(smp, counts.data(), &out.total_reads, &out.matched_reads);
+    if (frc == SGC_E_FORMAT) throw Panic(std::string(sgc_last_error()) + " in " + path);     // fxread panics on a malformed record
+    sgc_check(frc, "sgc_sample_finish");
+    if (st) {
+        st->finish_s = now_s() - t_fin;
+        st->reads = out.total_reads;
+        sgc_timing tm;
+        if (sgc_timing_read(ctx, &tm, 1) == SGC_OK) {
+            st->h2d_ms = tm.h2d_ms; st->ingest_ms = tm.pack_ms;
+            st->count_ms = tm.part_ms + tm.lookup_ms + tm.miss_ms + tm.hist_ms;
+        }
+        st->wall_s = now_s() - t_begin;
+    }
     for (size_t i = 0; i < counts.size(); i++)                                         // id-keyed fold, counter.rs:232-235
         if (counts[i]) out.by_id[library.ids[i]] += counts[i];
     return out;
 }
 
-void count(const CountOptions &opt) {
+void count(const CountOptions &opt_in) {
+    CountOptions opt = opt_in;
+    const double t_start = now_s();
     const Library library = Library::from_path(opt.library_path);                      // count.rs:87
     if (opt.genemap) {                                                                 // count.rs:90-95
         if (const std::string *missing = opt.genemap->missing_alias(library))
@@ -499,32 +665,43 @@ void count(const CountOptions &opt) {
                         "of your reference sequences (i.e. extracting the variable region of the sgRNA or reducing the length of "
                         "the adapters.)");
     }
+    const double t_lib = now_s();
     // device tables: Library + (unless exact) Permuter, count.rs:103-107.  One context per worker thread (its own
     // stream, scratch and table copy — ~0.15 GB at 100k guides), dealt round-robin over the visible GPUs: with -t N
     // the samples of one GPU overlap too (one sample's inflate and parse run beside another's kernels), which is
     // what the reference's rayon pool over samples gives on CPU cores.
     int n_dev = sgc_device_count();
     if (n_dev < 1) n_dev = 1;                                     // sgc_init below reports the missing device
-    if (const char *v = getenv("SGCOUNT_DEVICES")) n_dev = std::max(1, std::min(n_dev, atoi(v)));
+    if (opt.max_devices > 0) n_dev = std::min(n_dev, (int)opt.max_devices);
     const size_t n_workers = std::max<size_t>(1, std::min(opt.threads, opt.input_paths.size()));
     const size_t n_ctx = std::min(opt.input_paths.size(), std::max<size_t>((size_t)n_dev, n_workers));
+    if (opt.io_threads == 0) {
+        const size_t hw = std::max(1u, std::thread::hardware_concurrency());
+        opt.io_threads = std::max<size_t>(1, std::min<size_t>(8, hw / n_workers));
+    }
     std::string flat;
     flat.reserve(library.seqs.size() * library.size);
     for (const auto &s : library.seqs) flat += s;
     std::vector<sgc_ctx *> ctxs;
     struct CtxGuard { std::vector<sgc_ctx *> &v; ~CtxGuard() { for (auto c : v) sgc_free(c); } } cg{ctxs};
+    std::vector<int> ctx_dev;
     for (size_t k = 0; k < n_ctx; k++) {
         sgc_ctx *c = nullptr;
         sgc_check(sgc_init((int)(k % (size_t)n_dev), &c), "sgc_init");
         ctxs.push_back(c);
+        ctx_dev.push_back((int)(k % (size_t)n_dev));
         if (!opt.quiet && !opt.exact && k == 0) fprintf(stderr, "Generating Mismatch Library\n");
         sgc_check(sgc_set_library(c, (const uint8_t *)flat.data(), (uint32_t)library.seqs.size(), (uint32_t)library.size,
                                   !opt.exact), "sgc_set_library");
         if (!opt.quiet && !opt.exact && k == 0) fprintf(stderr, "Finished Mismatch Library\n");
+        if (!opt.stats_path.empty()) sgc_check(sgc_timing_enable(c, 1), "sgc_timing_enable");
     }
+    const double t_tables = now_s();
     // samples in parallel (count.rs:117-136: rayon over samples, pool size -t), results in input order
     const size_t n = opt.input_paths.size();
     std::vector<SampleCounts> results(n);
+    std::vector<SampleStats> stats(n);
+    std::vector<int> sample_dev(n, -1);
     std::vector<std::string> errors(n);
     std::vector<int> kinds(n, 0);
     std::atomic<size_t> next{0};
@@ -538,7 +715,9 @@ void count(const CountOptions &opt) {
             try {
                 if (!opt.quiet) fprintf(stderr, "Processing: %s\n", opt.sample_names[i].c_str());
                 std::lock_guard<std::mutex> lk(dev_mu[d]);      // one sample at a time per context
-                results[i] = count_sample(ctxs[d], opt.input_paths[i], opt.offsets[i], library, opt);
+                sample_dev[i] = ctx_dev[d];
+                results[i] = count_sample(ctxs[d], opt.input_paths[i], opt.offsets[i], library, opt,
+                                          opt.stats_path.empty() ? nullptr : &stats[i]);
                 if (!opt.quiet)                                                           // count.rs:34-43
                     fprintf(stderr, "Finished: %s; Fraction mapped: %.3f [%llu / %llu]\n", opt.sample_names[i].c_str(),
                             (double)results[i].matched_reads / (double)results[i].total_reads,
@@ -556,7 +735,27 @@ void count(const CountOptions &opt) {
         if (kinds[i] == 2) throw Panic(errors[i]);
         if (kinds[i] == 1) throw Error(errors[i]);
     }
+    const double t_counted = now_s();
     write_results(opt.output_path, results, library, opt.sample_names, opt.genemap, opt.include_zero);
+    const double t_end = now_s();
+    if (!opt.stats_path.empty()) {
+        FILE *f = fopen(opt.stats_path.c_str(), "wb");
+        if (!f) throw Error("cannot create the stats file: " + opt.stats_path);
+        fprintf(f, "{\"library_load_s\": %.6f, \"table_build_s\": %.6f, \"samples_s\": %.6f, \"table_write_s\": %.6f, \"total_s\": %.6f, "
+                   "\"devices\": %d, \"contexts\": %zu, \"worker_threads\": %zu, \"samples\": [",
+                t_lib - t_start, t_tables - t_lib, t_counted - t_tables, t_end - t_counted, t_end - t_start, n_dev, ctxs.size(), n_threads);
+        for (size_t i = 0; i < n; i++) {
+            const SampleStats &x = stats[i];
+            fprintf(f, "%s{\"device\": %d, \"reads\": %llu, \"text_bytes\": %llu, \"gz\": %s, \"text_path\": %s, \"reader_threads\": %zu, "
+                       "\"wall_s\": %.6f, \"read_busy_s\": %.6f, \"wait_for_text_s\": %.6f, \"push_s\": %.6f, \"wait_for_upload_s\": %.6f, "
+                       "\"finish_s\": %.6f, \"h2d_ms\": %.3f, \"ingest_kernels_ms\": %.3f, \"count_kernels_ms\": %.3f}",
+                    i ? ", " : "", sample_dev[i], (unsigned long long)x.reads, (unsigned long long)x.text_bytes, x.gz ? "true" : "false",
+                    x.text_path ? "true" : "false", x.reader_threads, x.wall_s, x.read_busy_s, x.read_wait_s, x.push_s,
+                    x.upload_wait_s, x.finish_s, x.h2d_ms, x.ingest_ms, x.count_ms);
+        }
+        fprintf(f, "]}\n");
+        fclose(f);
+    }
 }
 
 }  // namespace sgh

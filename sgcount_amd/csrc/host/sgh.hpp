@@ -13,10 +13,15 @@
 // Errors: the reference either returns anyhow errors (exit 1, "Error: ...") or panics (exit 101).  Here
 // both are C++ exceptions: sgh::Error (exit 1) and sgh::Panic (exit 101), with the reference's messages.
 #pragma once
+#include <zlib.h>
+
+#include <condition_variable>
 #include <cstdint>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -88,13 +93,63 @@ struct CountOptions {
     const GeneMap *genemap = nullptr;
     size_t threads = 1;
     bool device_pack = true;             // raw bytes → records on the GPU (else sgc_pack_reads_host)
-    bool device_parse = true;            // FASTQ inputs: ship text chunks, find record boundaries on the GPU
-    size_t chunk_bytes = 64u << 20;      // text chunk size for device_parse
+    bool device_parse = true;            // FASTQ inputs: ship text, find record boundaries on the GPU
+    size_t chunk_bytes = 64u << 20;      // bytes of text per slice (one upload) for device_parse
+    size_t io_threads = 0;               // reader threads per sample for plain FASTQ (0 = min(8, cores / worker threads))
     size_t batch_reads = 1u << 20;
+    std::string stats_path;              // if set: per-stage timings of the run as JSON (bench.py's e2e block)
+    size_t max_devices = 0;              // use at most this many of the visible GPUs (0 = all)
 };
 void count(const CountOptions &opt);                     // count.rs:74-148
-// text path of count(): byte offset at which a chunk of FASTQ text ends on a whole 4-line record (exposed for tests)
-size_t fastq_chunk_cut(const uint8_t *buf, size_t have, bool eof, const std::string &path);
+
+// ---- FASTQ text at speed (the byte source of count()'s text path) ----------------------------------------
+size_t count_newlines(const uint8_t *p, size_t n);
+
+struct SampleStats {                    // where one sample's wall time went (host side; device side from sgc_timing)
+    double wall_s = 0, read_busy_s = 0, read_wait_s = 0, push_s = 0, upload_wait_s = 0, finish_s = 0;
+    double h2d_ms = 0, ingest_ms = 0, count_ms = 0;
+    uint64_t text_bytes = 0, reads = 0;
+    size_t reader_threads = 0;
+    bool gz = false, text_path = false;
+};
+
+// Fills a small ring of (pinned) buffers with consecutive slices of a file's text and counts the newlines of every
+// slice on the way.  Plain files: `threads` readers pread() disjoint sub-ranges of a slice in parallel (page cache →
+// buffer is a memory copy, one core does ~5-10 GB/s of it).  gzip streams (by magic number): one inflating producer.
+// Every buffer has HEAD spare bytes in front of the slice, where the consumer parks the unfinished line of the
+// slice before.
+class TextFeeder {
+  public:
+    static constexpr size_t HEAD = 1u << 20;
+    TextFeeder(const std::string &path, size_t slice_bytes, size_t ring, size_t threads, void *(*alloc)(size_t),
+               void (*release)(void *));
+    ~TextFeeder();
+    // blocks until slice k (k = 0, 1, 2, ... in order) is in its buffer; eof = this is the last slice
+    bool acquire(size_t k, uint8_t *&data, size_t &len, uint64_t &newlines, bool &eof);
+    uint8_t *buffer_of(size_t k) const { return bufs[k % ring_n]; }     // base of slice k's buffer (slice data at + HEAD)
+    void release_below(size_t k);       // the buffers of slices < k may be refilled
+    uint8_t first_byte = 0;             // first byte of the text
+    bool is_gz = false;
+    size_t file_size = 0, n_threads = 1;
+    double busy_s = 0, wait_s = 0;      // Σ reader busy time; time the consumer waited for text
+  private:
+    struct Slot { size_t index = (size_t)-1, len = 0, pending = 0; uint64_t newlines = 0; bool ready = false, eof = false; };
+    void run_plain();
+    void run_gz();
+    void shutdown();
+    std::string path;
+    void (*free_fn)(void *);
+    int fd = -1;
+    gzFile gz = nullptr;
+    size_t slice = 0, ring_n = 0, n_slices_known = 0, next_job = 0, released = 0;
+    std::vector<uint8_t *> bufs;
+    std::vector<Slot> slots;
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool stop = false, failed = false;
+    std::string error;
+};
 int cli_main(int argc, char **argv);                     // main.rs:142-203; returns the process exit code
 
 }  // namespace sgh

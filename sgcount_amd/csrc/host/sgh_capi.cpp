@@ -1,6 +1,7 @@
 // sgh_capi.cpp — flat C entry points over the C++ host (for the Python tests; libsgcount_host.so).
 // Every function returns 0 on success, 1 for an sgh::Error, 101 for an sgh::Panic (the reference's exit codes)
 // and leaves the message in sgh_last_error().
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -129,9 +130,41 @@ int sgh_fastx_stats(const char *path, uint64_t *n_records, uint64_t *seq_bytes, 
     });
 }
 
-// the text path's chunk cutter (sgh.cpp fastq_chunk_cut): cut_out = bytes that form whole 4-line records
-int sgh_fastq_chunk_cut(const uint8_t *buf, uint64_t have, int eof, uint64_t *cut_out) {
-    return guard([&] { *cut_out = sgh::fastq_chunk_cut(buf, (size_t)have, eof != 0, "<buffer>"); });
+// the text path's byte source (sgh.cpp TextFeeder) with malloc'd buffers: walks the whole file the way count() does
+// (cut at the last newline, carry the rest) and reports what it would push: parts, bytes, lines, and a checksum of
+// (first_line, bytes, newlines) per part folded with the bytes themselves
+int sgh_text_feeder_walk(const char *path, uint64_t slice_bytes, uint64_t threads, uint64_t *parts_out, uint64_t *bytes_out,
+                         uint64_t *lines_out, uint64_t *fnv_out, int *first_byte_out, int *is_gz_out) {
+    return guard([&] {
+        sgh::TextFeeder feed(path, (size_t)slice_bytes, 3, (size_t)threads, malloc, free);
+        *first_byte_out = feed.first_byte; *is_gz_out = feed.is_gz;
+        uint64_t parts = 0, bytes = 0, first_line = 0, h = 1469598103934665603ull;
+        size_t carry = 0;
+        for (size_t k = 0;; k++) {
+            uint8_t *data; size_t len; uint64_t nl; bool eof;
+            feed.acquire(k, data, len, nl, eof);
+            if (sgh::count_newlines(data, len) != nl) throw sgh::Error("newline count of a slice is wrong");
+            uint8_t *part = data - carry;
+            size_t part_len = carry + len, tail = 0;
+            if (!eof) {
+                const void *p = len ? memrchr(data, '\n', len) : nullptr;
+                const size_t keep = p ? (size_t)((const uint8_t *)p - part) + 1 : 0;
+                tail = part_len - keep;
+                if (tail > sgh::TextFeeder::HEAD) throw sgh::Error("line too long");
+                memcpy(feed.buffer_of(k + 1) + sgh::TextFeeder::HEAD - tail, part + keep, tail);
+                part_len = keep;
+            }
+            if (part_len) {
+                parts++; bytes += part_len;
+                for (size_t i = 0; i < part_len; i++) { h ^= part[i]; h *= 1099511628211ull; }
+                first_line += nl + (part[part_len - 1] != '\n' ? 1 : 0);
+            }
+            feed.release_below(k);
+            carry = tail;
+            if (eof) break;
+        }
+        *parts_out = parts; *bytes_out = bytes; *lines_out = first_line; *fnv_out = h;
+    });
 }
 
 }  // extern "C"

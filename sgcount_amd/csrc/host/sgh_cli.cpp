@@ -28,6 +28,10 @@ static const char *USAGE =
     "  -z, --include-zero                    Include zero count sgRNAs in output table\n"
     "      --pack <host|device|fastq>        Where reads are parsed/packed: host packer, GPU packer on host-parsed reads,\n"
     "                                        or FASTQ text parsed on the GPU [default: fastq]\n"
+    "      --io-threads <N>                  Reader threads per sample for plain FASTQ text [default: min(8, cores/threads)]\n"
+    "      --chunk-mb <MB>                   Text per upload [default: 64]\n"
+    "      --devices <N>                     Use at most N of the visible GPUs [default: all]\n"
+    "      --stats-json <PATH>               Write per-stage timings of the run as JSON\n"
     "  -h, --help                            Print help\n"
     "  -V, --version                         Print version\n";
 
@@ -75,6 +79,10 @@ int cli_main(int argc, char **argv) {
                 opt.device_pack = v != "host";
                 opt.device_parse = v == "fastq";
             }
+            else if (a == "--io-threads") opt.io_threads = to_num(need(i, "--io-threads"), "--io-threads");
+            else if (a == "--chunk-mb") opt.chunk_bytes = to_num(need(i, "--chunk-mb"), "--chunk-mb") << 20;
+            else if (a == "--devices") opt.max_devices = to_num(need(i, "--devices"), "--devices");
+            else if (a == "--stats-json") opt.stats_path = need(i, "--stats-json");
             else if (a == "-h" || a == "--help") { fputs(USAGE, stdout); return 0; }
             else if (a == "-V" || a == "--version") { puts("sgcount-hip 0.1.0 (count path of sgcount 0.1.35)"); return 0; }
             else { fprintf(stderr, "error: unexpected argument '%s' found\n\n%s", a.c_str(), USAGE); return 2; }

@@ -30,7 +30,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
                         std::string(#expr) + ": " + hipGetErrorString(e_));                    \
     } while (0)
 
-enum { T_LOOKUP = 0, T_HIST = 1, T_PACK = 2, T_PART = 3, T_MISS = 4, T_KINDS = 5 };
+enum { T_LOOKUP = 0, T_HIST = 1, T_PACK = 2, T_PART = 3, T_MISS = 4, T_H2D = 5, T_KINDS = 6 };
 
 struct sgc_ctx {
     int device = 0;
@@ -56,6 +56,15 @@ struct sgc_ctx {
     void *d_csmall = nullptr; size_t csmall_cap = 0;    // their histograms / partition starts / extents
     // scratch (grown on demand, stream-ordered reuse)
     void *d_stage = nullptr; size_t stage_cap = 0;      // host -> device staging of pushed buffers
+    // FASTQ text pushed from host memory: uploads run on their own stream into two alternating device buffers, so that
+    // the upload of part k+1 overlaps the ingest and count kernels of part k
+    hipStream_t copy_stream = nullptr;
+    void *d_text[2] = {nullptr, nullptr}; size_t text_cap[2] = {0, 0};
+    hipEvent_t ev_use[2] = {nullptr, nullptr};          // the ingest kernels that read d_text[i] are done
+    bool use_recorded[2] = {false, false};
+    static constexpr int UP_RING = 8;
+    hipEvent_t ev_up[UP_RING] = {};                     // upload k is complete: ev_up[k % UP_RING]
+    uint64_t n_up = 0;                                  // uploads issued so far
     void *d_aux = nullptr; size_t aux_cap = 0;          // offsets / secondary staging
     uint64_t *d_recs = nullptr; size_t recs_cap = 0;    // records produced by the on-device packers
     void *d_gids = nullptr; size_t gids_cap = 0;        // per-read guide ids between the lookup and histogram kernels
@@ -68,6 +77,8 @@ struct sgc_ctx {
     uint32_t dbg = 0;           // timing-only ablation flags (results are wrong when non-zero)
     uint32_t k1_wgs = 256;      // workgroups of the partition kernel: few, so that few half-empty blocks are left open
     uint64_t max_chunk = 1ull << 27;   // records per internal pass (bounds the scratch buffers)
+    bool host_build = false;           // build the single-mismatch table on the host (sgc_tables.cpp) instead of the GPU
+    uint32_t perm_bloom_bits = 8;      // Bloom bits per child of the single-mismatch filter
     // timing
     bool timing = false;
     struct span_ev { hipEvent_t a, b; int kind; bool owns_a; };
@@ -82,6 +93,8 @@ struct sgc_sample {
     uint32_t *d_c32 = nullptr;
     unsigned long long *d_c64 = nullptr;
     unsigned long long *d_matched = nullptr;
+    unsigned long long *d_err = nullptr;   // [0] = ~0 - (first line whose marker byte is wrong), 0 = none; [1] = flags (FASTQ ingest)
+    bool fastq_pushed = false;
     uint64_t total = 0;
     uint64_t since_fold = 0;     // reads counted into d_c32 since the last fold (u32 overflow guard)
     size_t state_bytes = 0;
@@ -114,8 +127,9 @@ static void timing_drain(sgc_ctx *c) {
             else if (s.kind == T_HIST) c->acc.hist_ms += ms;
             else if (s.kind == T_PART) c->acc.part_ms += ms;
             else if (s.kind == T_MISS) c->acc.miss_ms += ms;
+            else if (s.kind == T_H2D) c->acc.h2d_ms += ms;
             else c->acc.pack_ms += ms;
-            c->acc.launches++;
+            if (s.kind != T_H2D) c->acc.launches++;
         }
         if (s.owns_a) c->free_events.push_back(s.a);
         c->free_events.push_back(s.b);
@@ -127,16 +141,16 @@ static void timing_drain(sgc_ctx *c) {
 // is reused), which is only right when nothing was enqueued in between — it saves one event packet (~4 us of
 // stream time) between back-to-back kernels.
 struct timed {
-    sgc_ctx *c; int kind; hipEvent_t a = nullptr, b = nullptr; bool owns_a = true;
-    timed(sgc_ctx *c_, int k, bool chain = false) : c(c_), kind(k) {
+    sgc_ctx *c; int kind; hipEvent_t a = nullptr, b = nullptr; bool owns_a = true; hipStream_t st;
+    timed(sgc_ctx *c_, int k, bool chain = false, hipStream_t other = nullptr) : c(c_), kind(k), st(other ? other : c_->stream) {
         if (!c->timing) return;
-        if (chain && !c->pending.empty()) { a = c->pending.back().b; owns_a = false; }
-        else { a = ev_get(c); if (a) hipEventRecord(a, c->stream); }
+        if (chain && !other && !c->pending.empty() && c->pending.back().kind != T_H2D) { a = c->pending.back().b; owns_a = false; }
+        else { a = ev_get(c); if (a) hipEventRecord(a, st); }
         b = ev_get(c);
     }
     ~timed() {
         if (!c->timing || !a || !b) return;
-        hipEventRecord(b, c->stream);
+        hipEventRecord(b, st);
         c->pending.push_back({a, b, kind, owns_a});
         if (c->pending.size() >= 256) timing_drain(c);
     }
@@ -267,7 +281,10 @@ int sgc_init(int device, sgc_ctx **out) {
         sgc_free(c);
         return fail(SGC_E_HIP, "sgc_init: cannot create the side stream");
     }
-    if (const char *v = getenv("SGC_VARIANT")) c->variant = atoi(v);
+    bool ok = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2 && ok; i++) ok = hipEventCreateWithFlags(&c->ev_use[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < sgc_ctx::UP_RING && ok; i++) ok = hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { sgc_free(c); return fail(SGC_E_HIP, "sgc_init: cannot create the upload stream"); }
     *out = c;
     return SGC_OK;
 }
@@ -310,6 +327,9 @@ void sgc_free(sgc_ctx *c) {
     if (c->d_cbuf) hipFree(c->d_cbuf);
     if (c->d_csmall) hipFree(c->d_csmall);
     if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
+    if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
+    for (int i = 0; i < 2; i++) { if (c->d_text[i]) hipFree(c->d_text[i]); if (c->ev_use[i]) hipEventDestroy(c->ev_use[i]); }
+    for (int i = 0; i < sgc_ctx::UP_RING; i++) if (c->ev_up[i]) hipEventDestroy(c->ev_up[i]);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
@@ -347,6 +367,12 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
         if (value < 1 || value > (int64_t)0xF0000000ll) return fail(SGC_E_ARG, "max_chunk out of range");
         c->max_chunk = (uint64_t)value; return SGC_OK;
     }
+    if (!strcmp(key, "host_build")) { c->host_build = value != 0; return SGC_OK; }          // takes effect at the next sgc_set_library
+    if (!strcmp(key, "perm_bloom_bits")) {
+        if (value < 1 || value > 64) return fail(SGC_E_ARG, "perm_bloom_bits must be 1..64");
+        c->perm_bloom_bits = (uint32_t)value; return SGC_OK;
+    }
+    if (!strcmp(key, "print_occupancy")) { sgc_core_print_occupancy(); return SGC_OK; }
     if (!strcmp(key, "per_lane")) {
         if (value != 1 && value != 2 && value != 4) return fail(SGC_E_ARG, "per_lane must be 1, 2 or 4");
         c->per_lane = (int)value; return SGC_OK;
@@ -397,12 +423,11 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
     c->v_perm = sgc_table_view{nullptr, nullptr, 0, h_lib.gid_bits, 0, 0};
     c->perm_entries = 0;
     if (enable_1mm) {
-        uint32_t bpk = 8;                    // Bloom bits per child, rounded up to a power-of-two word count: 6.0 M children -> 8 MiB
-        if (const char *v = getenv("SGC_PERM_BLOOM_BITS")) bpk = (uint32_t)std::max(1, atoi(v));
+        const uint32_t bpk = c->perm_bloom_bits;   // Bloom bits per child, rounded up to a power-of-two word count: 6.0 M children -> 8 MiB
         const uint64_t n_children = (uint64_t)n * 3 * L;
         const uint32_t bloom_log2 = sgc_bloom_log2_words(n_children, bpk, 10, 24);
         std::vector<uint64_t> amb;
-        const bool device_build = h_lib.gid_bits != 0 && !getenv("SGC_HOST_BUILD");
+        const bool device_build = h_lib.gid_bits != 0 && !c->host_build;
         if (device_build) {
             // children, their table, its filter and the ambiguity masks are built on the GPU (sgc_build.hip)
             const uint32_t pl2 = sgc_permute_log2_slots(n_children);
@@ -447,22 +472,28 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
             const uint32_t ca = (L - 2) / 2;
             sgc_host_core hc[2];
             if (sgc_build_core_index(keys, L, 2, ca, hc[0]) && sgc_build_core_index(keys, L, 2 + ca, L - 2 - ca, hc[1])) {
-                for (int k = 0; k < 2; k++) {
-                    HIP_TRY(hipMalloc((void **)&c->d_core_ents[k], hc[k].ents.size() * 8));
-                    HIP_TRY(hipMalloc((void **)&c->d_core_gids[k], hc[k].gids.size() * 4));
-                    HIP_TRY(hipMalloc((void **)&c->d_core_starts[k], hc[k].starts.size() * 2));
-                    HIP_TRY(hipMemcpyAsync(c->d_core_ents[k], hc[k].ents.data(), hc[k].ents.size() * 8, hipMemcpyHostToDevice, c->stream));
-                    HIP_TRY(hipMemcpyAsync(c->d_core_gids[k], hc[k].gids.data(), hc[k].gids.size() * 4, hipMemcpyHostToDevice, c->stream));
-                    HIP_TRY(hipMemcpyAsync(c->d_core_starts[k], hc[k].starts.data(), hc[k].starts.size() * 2, hipMemcpyHostToDevice, c->stream));
+                hipError_t e = hipSuccess;
+                for (int k = 0; k < 2 && e == hipSuccess; k++) {
+                    e = hipMalloc((void **)&c->d_core_ents[k], hc[k].ents.size() * 8);
+                    if (e == hipSuccess) e = hipMalloc((void **)&c->d_core_gids[k], hc[k].gids.size() * 4);
+                    if (e == hipSuccess) e = hipMalloc((void **)&c->d_core_starts[k], hc[k].starts.size() * 2);
+                    if (e == hipSuccess) e = hipMemcpyAsync(c->d_core_ents[k], hc[k].ents.data(), hc[k].ents.size() * 8, hipMemcpyHostToDevice, c->stream);
+                    if (e == hipSuccess) e = hipMemcpyAsync(c->d_core_gids[k], hc[k].gids.data(), hc[k].gids.size() * 4, hipMemcpyHostToDevice, c->stream);
+                    if (e == hipSuccess) e = hipMemcpyAsync(c->d_core_starts[k], hc[k].starts.data(), hc[k].starts.size() * 2, hipMemcpyHostToDevice, c->stream);
                     c->v_core[k] = sgc_core_view{c->d_core_ents[k], c->d_core_gids[k], c->d_core_starts[k], hc[k].log2_p, hc[k].cs, hc[k].cl, 0};
                 }
-                if (!device_build) {
-                    HIP_TRY(hipMalloc((void **)&c->d_amb, amb.size() * 8));
-                    HIP_TRY(hipMemcpyAsync(c->d_amb, amb.data(), amb.size() * 8, hipMemcpyHostToDevice, c->stream));
+                if (e == hipSuccess && !device_build) {
+                    e = hipMalloc((void **)&c->d_amb, amb.size() * 8);
+                    if (e == hipSuccess) e = hipMemcpyAsync(c->d_amb, amb.data(), amb.size() * 8, hipMemcpyHostToDevice, c->stream);
                 }
-                HIP_TRY(hipStreamSynchronize(c->stream));
+                // the host vectors above must outlive the copies: synchronise before they go out of scope, error or not
+                const hipError_t e2 = hipStreamSynchronize(c->stream);
+                if (e == hipSuccess) e = e2;
+                if (e != hipSuccess) {
+                    free_tables(c);                       // nothing of a half-built library stays behind
+                    return fail(e == hipErrorOutOfMemory ? SGC_E_OOM : SGC_E_HIP, std::string("sgc_set_library: core index upload: ") + hipGetErrorString(e));
+                }
                 c->has_core = true;
-                if (getenv("SGC_OCC_DBG")) sgc_core_print_occupancy();
             }
         }
     }
@@ -551,12 +582,13 @@ int sgc_sample_begin(sgc_ctx *c, sgc_sample **out, int reverse, uint32_t offset,
     sgc_sample *s = new (std::nothrow) sgc_sample();
     if (!s) return fail(SGC_E_OOM, "sgc_sample_begin: out of host memory");
     s->ctx = c; s->reverse = reverse != 0; s->offset = offset; s->recursion = position_recursion != 0;
-    // one allocation: u64 counts[n] | u64 matched | u64 spare | u32 counts[n]  (one memset resets a sample)
-    s->state_bytes = (size_t)c->n * 8 + 16 + (size_t)c->n * 4;
+    // one allocation: u64 counts[n] | u64 matched | u64 spare | u64 err[2] | u32 counts[n]  (one memset resets a sample)
+    s->state_bytes = (size_t)c->n * 8 + 32 + (size_t)c->n * 4;
     hipError_t e = hipMalloc((void **)&s->d_c64, s->state_bytes);
     if (e != hipSuccess) { s->d_c64 = nullptr; sgc_sample_free(s); return fail(SGC_E_OOM, std::string("sgc_sample_begin: ") + hipGetErrorString(e)); }
     s->d_matched = s->d_c64 + c->n;
-    s->d_c32 = (uint32_t *)(s->d_c64 + c->n + 2);
+    s->d_err = s->d_c64 + c->n + 2;
+    s->d_c32 = (uint32_t *)(s->d_c64 + c->n + 4);
     int rc = sgc_sample_reset(s);
     if (rc) { sgc_sample_free(s); return rc; }
     *out = s;
@@ -568,7 +600,7 @@ int sgc_sample_reset(sgc_sample *s) {
     sgc_ctx *c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(s->d_c64, 0, s->state_bytes, c->stream));
-    s->total = 0; s->since_fold = 0;
+    s->total = 0; s->since_fold = 0; s->fastq_pushed = false;
     return SGC_OK;
 }
 
@@ -629,56 +661,123 @@ int sgc_sample_push_reads(sgc_sample *s, const uint8_t *seqs, const uint64_t *of
     return count_records(s, c->d_recs, n);
 }
 
+// One part of a FASTQ stream: whole lines, starting at global line number first_line (any phase of the 4-line
+// cycle).  n_newlines == UINT64_MAX: unknown — the device counts and the call waits for the count.
+static int push_fastq_part(sgc_sample *s, const uint8_t *text, uint64_t n_bytes, int where, uint64_t first_line,
+                           uint64_t n_newlines, uint64_t n_lines, uint64_t *n_records_out, uint64_t *n_lines_out) {
+    sgc_ctx *c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t tiles = sgc_fastq_tiles(n_bytes);
+    int rc = ensure(&c->d_aux, &c->aux_cap, ((size_t)tiles + 1) * 4);
+    if (rc) return rc;
+    const uint8_t *d_text = text;
+    int slot = -1;
+    if (where == SGC_MEM_HOST) {
+        // upload on the copy stream into the buffer the part before last used (its ingest kernels must be done)
+        slot = (int)(c->n_up & 1u);
+        if (n_bytes > c->text_cap[slot]) {
+            if (c->use_recorded[slot]) HIP_TRY(hipEventSynchronize(c->ev_use[slot]));
+            rc = ensure(&c->d_text[slot], &c->text_cap[slot], n_bytes);
+            if (rc) return rc;
+        }
+        hipEvent_t up = c->ev_up[c->n_up % sgc_ctx::UP_RING];
+        if (c->n_up >= (uint64_t)sgc_ctx::UP_RING) HIP_TRY(hipEventSynchronize(up));      // at most UP_RING uploads in flight
+        if (c->use_recorded[slot]) HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_use[slot], 0));
+        {
+            timed t(c, T_H2D, false, c->copy_stream);
+            HIP_TRY(hipMemcpyAsync(c->d_text[slot], text, n_bytes, hipMemcpyHostToDevice, c->copy_stream));
+        }
+        HIP_TRY(hipEventRecord(up, c->copy_stream));
+        HIP_TRY(hipStreamWaitEvent(c->stream, up, 0));
+        c->n_up++;
+        d_text = (const uint8_t *)c->d_text[slot];
+    } else if (where != SGC_MEM_DEVICE) {
+        return fail(SGC_E_ARG, "sgc_sample_push_fastq: where must be SGC_MEM_HOST or SGC_MEM_DEVICE");
+    }
+    uint32_t *tile_scratch = (uint32_t *)c->d_aux;
+    uint64_t lines = n_lines;
+    { timed t(c, T_PACK); sgc_launch_fastq_count(c->stream, d_text, n_bytes, tile_scratch); }
+    if (n_newlines == UINT64_MAX) {
+        uint32_t nl = 0; uint8_t last = 0;
+        HIP_TRY(hipMemcpyAsync(&nl, tile_scratch + tiles, 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(&last, d_text + n_bytes - 1, 1, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        n_newlines = nl;
+        lines = (uint64_t)nl + (last == '\n' ? 0 : 1);
+    }
+    if (n_lines_out) *n_lines_out = lines;
+    // records = sequence lines (line % 4 == 1) of the part.  A last line without its '\n' can only be a quality line
+    // in a well-formed stream, so the announced newline count decides (a truncated record is the caller's to report).
+    const uint64_t n_records = sgc_fastq_records(first_line, lines);
+    void *p = c->d_recs; size_t cap = c->recs_cap;
+    rc = ensure(&p, &cap, (size_t)(n_records ? n_records : 1) * (c->rec16 ? 16 : 8));
+    c->d_recs = (uint64_t *)p; c->recs_cap = cap;
+    if (rc) return rc;
+    {
+        timed t(c, T_PACK, true);
+        sgc_launch_fastq_pack(c->stream, d_text, n_bytes, tile_scratch, first_line, (uint32_t)n_newlines, (uint32_t)lines, c->L, c->rec16,
+                              s->reverse, s->offset, s->recursion, c->d_recs, s->d_err);
+    }
+    HIP_TRY(hipGetLastError());
+    if (slot >= 0) { HIP_TRY(hipEventRecord(c->ev_use[slot], c->stream)); c->use_recorded[slot] = true; }
+    s->fastq_pushed = true;
+    if (n_records_out) *n_records_out = n_records;
+    return count_records(s, c->d_recs, n_records);
+}
+
 int sgc_sample_push_fastq(sgc_sample *s, const uint8_t *text, uint64_t n_bytes, int where, uint64_t *n_records_out) {
     if (!s || (!text && n_bytes)) return fail(SGC_E_ARG, "sgc_sample_push_fastq: NULL argument");
     if (n_records_out) *n_records_out = 0;
     if (n_bytes == 0) return SGC_OK;
     if (n_bytes > 0xFFF00000ull) return fail(SGC_E_ARG, "sgc_sample_push_fastq: chunk larger than 4 GiB");
-    sgc_ctx *c = s->ctx;
-    HIP_TRY(hipSetDevice(c->device));
-    const uint8_t *d_text = text;
-    if (where == SGC_MEM_HOST) {
-        int rc = ensure(&c->d_stage, &c->stage_cap, n_bytes);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(c->d_stage, text, n_bytes, hipMemcpyHostToDevice, c->stream));
-        d_text = (const uint8_t *)c->d_stage;
-    } else if (where != SGC_MEM_DEVICE) {
-        return fail(SGC_E_ARG, "sgc_sample_push_fastq: where must be SGC_MEM_HOST or SGC_MEM_DEVICE");
-    }
-    const uint32_t tiles = sgc_fastq_tiles(n_bytes);
-    int rc = ensure(&c->d_aux, &c->aux_cap, ((size_t)tiles + 1) * 4);
+    uint64_t lines = 0;
+    const int rc = push_fastq_part(s, text, n_bytes, where, 0, UINT64_MAX, UINT64_MAX, n_records_out, &lines);
     if (rc) return rc;
-    // a FASTQ record is at least 8 bytes ("@\n\n+\n\n" plus one base and quality): bound the record buffer
-    const uint64_t max_recs = n_bytes / 7 + 1;
-    void *p = c->d_recs; size_t cap = c->recs_cap;
-    rc = ensure(&p, &cap, (size_t)max_recs * (c->rec16 ? 16 : 8));
-    c->d_recs = (uint64_t *)p; c->recs_cap = cap;
-    if (rc) return rc;
-    {
-        timed t(c, T_PACK);
-        sgc_launch_fastq(c->stream, d_text, n_bytes, (uint32_t *)c->d_aux, c->L, c->rec16, s->reverse, s->offset,
-                         s->recursion, c->d_recs);
-    }
-    HIP_TRY(hipGetLastError());
-    uint32_t n_newlines = 0;
-    HIP_TRY(hipMemcpyAsync(&n_newlines, (uint32_t *)c->d_aux + tiles, 4, hipMemcpyDeviceToHost, c->stream));
-    uint8_t last = 0;
-    HIP_TRY(hipMemcpyAsync(&last, d_text + n_bytes - 1, 1, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    const uint64_t lines = (uint64_t)n_newlines + (last == '\n' ? 0 : 1);
     if (lines % 4 != 0)
         return fail(SGC_E_ARG, "sgc_sample_push_fastq: the chunk does not hold whole 4-line records (" +
                                    std::to_string(lines) + " lines)");
-    const uint64_t n_records = lines / 4;
-    if (n_records_out) *n_records_out = n_records;
-    return count_records(s, c->d_recs, n_records);
+    return SGC_OK;
+}
+
+int sgc_sample_push_fastq_part(sgc_sample *s, const uint8_t *text, uint64_t n_bytes, int where, uint64_t first_line,
+                               uint64_t n_newlines, uint64_t *n_records_out) {
+    if (!s || (!text && n_bytes)) return fail(SGC_E_ARG, "sgc_sample_push_fastq_part: NULL argument");
+    if (n_records_out) *n_records_out = 0;
+    if (n_bytes == 0) return SGC_OK;
+    if (n_bytes > 0xFFF00000ull) return fail(SGC_E_ARG, "sgc_sample_push_fastq_part: part larger than 4 GiB");
+    if (n_newlines != UINT64_MAX && n_newlines > n_bytes) return fail(SGC_E_ARG, "sgc_sample_push_fastq_part: more newlines than bytes");
+    uint64_t lines = n_newlines;
+    if (n_newlines != UINT64_MAX && where == SGC_MEM_HOST && text[n_bytes - 1] != '\n') lines++;      // the stream's last line
+    return push_fastq_part(s, text, n_bytes, where, first_line, n_newlines, lines, n_records_out, nullptr);
+}
+
+int sgc_sample_wait_uploads(sgc_sample *s, uint32_t max_pending) {
+    if (!s) return fail(SGC_E_ARG, "sgc_sample_wait_uploads: NULL");
+    sgc_ctx *c = s->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    if (max_pending >= (uint32_t)sgc_ctx::UP_RING) return SGC_OK;     // never more than UP_RING in flight anyway
+    if (c->n_up > max_pending) HIP_TRY(hipEventSynchronize(c->ev_up[(c->n_up - 1 - max_pending) % sgc_ctx::UP_RING]));
+    return SGC_OK;
+}
+
+// marker bytes / newline count reported by the ingest kernels (after a synchronisation of the stream)
+static int check_fastq_errors(sgc_sample *s) {
+    if (!s->fastq_pushed) return SGC_OK;
+    sgc_ctx *c = s->ctx;
+    unsigned long long e[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(e, s->d_err, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (e[1] & 1ull) return fail(SGC_E_FORMAT, "FASTQ text: the newline count announced for a part differs from its contents");
+    if (e[0]) return fail(SGC_E_FORMAT, "malformed FASTQ record: line " + std::to_string(~0ull - e[0]) +
+                                           " does not start with its marker byte ('@' header / '+' separator)");
+    return SGC_OK;
 }
 
 int sgc_sample_sync(sgc_sample *s) {
     if (!s) return fail(SGC_E_ARG, "sgc_sample_sync: NULL");
     HIP_TRY(hipSetDevice(s->ctx->device));
     HIP_TRY(hipStreamSynchronize(s->ctx->stream));
-    return SGC_OK;
+    return check_fastq_errors(s);
 }
 
 int sgc_sample_flush(sgc_sample *s) {
@@ -715,7 +814,7 @@ int sgc_sample_finish(sgc_sample *s, uint64_t *counts, uint64_t *total_reads, ui
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (total_reads) *total_reads = s->total;
     if (matched_reads) *matched_reads = m;
-    return SGC_OK;
+    return check_fastq_errors(s);
 }
 
 int sgc_timing_enable(sgc_ctx *c, int on) {

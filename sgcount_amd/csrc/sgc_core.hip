@@ -482,7 +482,7 @@ void sgc_launch_core(hipStream_t st, uint32_t L, const sgc_table_view &lib, cons
                        (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, cb, (uint32_t *)nullptr, counts, matched, dbg);
 }
 
-// diagnostic (SGC_OCC_DBG=1 at sgc_set_library): resident workgroups per CU as the runtime computes them
+// diagnostic (sgc_set_option "print_occupancy"): resident workgroups per CU as the runtime computes them
 void sgc_core_print_occupancy() {
     int a = -1, b = -1, c = -1, d = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_core<false>, KC_THREADS, 0);

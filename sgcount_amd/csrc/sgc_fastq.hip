@@ -1,26 +1,37 @@
 // sgc_fastq.hip — FASTQ ingest on the GPU: record boundaries, window extraction and 2-bit packing from raw
 // FASTQ text resident in HBM (replaces fxread + Counter::apply_trim, reference src/counter.rs:144-204, for the
-// sgc_sample_push_fastq entry point), and the packer for raw reads (bytes + offsets).
+// sgc_sample_push_fastq* entry points), and the packer for raw reads (bytes + offsets).
 //
-// FASTQ is four lines per record, so record boundaries are a matter of counting newlines:
+// FASTQ is four lines per record, so record boundaries are a matter of counting newlines.  A *part* of a FASTQ
+// stream is a run of whole lines that starts at (global) line number first_line — any phase of the 4-line cycle:
 //   pass A  k_fastq_count   per 64 KiB tile: number of '\n'                      (reads the text once)
 //           k_scan_tiles    exclusive prefix over the tiles (one workgroup)
-//   pass B  k_fastq_pack    per tile: the tile is staged in LDS; global line number of every '\n'; the lane that
-//                           owns the newline ENDING A SEQUENCE LINE (line % 4 == 1) finds the line start, extracts
-//                           the L+2-base span at the sample's offset from LDS and writes record r = line / 4
-// The text chunk must start at a record boundary and hold whole records; a missing final '\n' is tolerated.
+//   pass B  k_fastq_pack    per tile: the tile (+ a halo of o + L + 2 bytes) is staged in LDS with coalesced
+//                           16-byte loads; a 64-bit newline mask per 64 bytes + one workgroup scan give every
+//                           newline its line number; the marker bytes ('@' at lines 4k, '+' at lines 4k + 2)
+//                           are verified; the lanes whose newline opens (forward strand) or closes (reverse
+//                           strand) a sequence line list it; one lane per listed line then packs the record
+//                           from LDS.  Only o + L + 2 bytes of a sequence line are ever needed: the forward
+//                           strand reads them from the line start (owner: the tile where the line starts), the
+//                           reverse strand from the line end (owner: the tile where it ends), so the halo is
+//                           bounded by the offset and not by the read length.
+// A '\r' before the '\n' belongs to the line terminator (CRLF files; fxread's behaviour is unpinned — DESIGN.md §2).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
 
+#include "sgc_device.h"
 #include "sgc_format.h"
 #include "sgc_kernels.h"
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 #define FQ_THREADS 1024u
-#define FQ_SUB 4u                           // sub-tiles per tile; one sub-tile = 16 bytes per lane
-#define FQ_TILE (FQ_THREADS * 16u * FQ_SUB) // 64 KiB
+#define FQ_TILE 65536u                      // bytes per tile: 64 per lane
+#define FQ_HALO_MAX 1024u                   // bytes staged beyond the tile (multiple of 64; two workgroups per CU must fit
+                                            // 160 KiB of LDS); an offset beyond it makes the owning lanes read global memory
+#define FQ_CAP 1024u                        // sequence lines listed per round (a tile of tiny records takes several rounds)
+#define FQ_PIECES ((FQ_TILE + FQ_HALO_MAX) / 16u)
 
 // 16-bit mask of '\n' among the 16 bytes at text[base ..) (bytes past n read as 0); optionally stages them in LDS
 __device__ __forceinline__ uint32_t nl_mask16(const uint8_t *__restrict__ text, uint64_t base, uint64_t n, uint8_t *stage) {
@@ -31,14 +42,11 @@ __device__ __forceinline__ uint32_t nl_mask16(const uint8_t *__restrict__ text, 
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            // zero-byte detection on (w ^ 0x0A0A0A0A) as a cheap "any newline in this word?" test (it may also
-            // fire for a 0x0B right after a newline, so the bytes are then checked one by one)
+            // exact per-byte test: bit 7 of every byte of y is set iff that byte of x is zero (no carries between bytes)
             const uint32_t x = w[k] ^ 0x0A0A0A0Au;
-            if ((x - 0x01010101u) & ~x & 0x80808080u) {
-#pragma unroll
-                for (int b = 0; b < 4; b++)
-                    if (((w[k] >> (8 * b)) & 0xFFu) == 0x0Au) m |= 1u << (4 * k + b);
-            }
+            const uint32_t y = ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;
+            // gather the four bit-7 flags into 4 adjacent bits
+            m |= (((y >> 7) * 0x00204081u) >> 21 & 0xFu) << (4 * k);
         }
     } else {
         for (uint32_t k = 0; k < 16; k++) {
@@ -50,57 +58,6 @@ __device__ __forceinline__ uint32_t nl_mask16(const uint8_t *__restrict__ text, 
     return m;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Cooperative packing: the L+2 bytes of one read's span are classified by L+2 lanes of a half-wave at once
-// (wave ballots give the 2-bit codes and the non-ACGT masks), instead of one lane looping over them.  Same bits
-// as sgc_pack_one (sgc_format.h); all lanes of the half-wave return the same (span, status).
-// s: start of the read (LDS or global), n: its length.  Must be called by all 64 lanes of the wave; the two
-// halves may work on different reads (or idle with n = 0, s = any valid pointer).
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t spread_bits(uint32_t x) {       // bit i -> bit 2i
-    uint64_t v = x;
-    v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
-    v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
-    v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
-    v = (v | (v << 2)) & 0x3333333333333333ull;
-    v = (v | (v << 1)) & 0x5555555555555555ull;
-    return v;
-}
-
-template <class Ptr>
-__device__ __forceinline__ void pack_coop(Ptr s, uint64_t n, uint32_t L, int reverse, uint32_t o, int recursion,
-                                          uint64_t &span, uint64_t &status) {
-    const uint32_t lane = threadIdx.x & 63u, w = lane & 31u, half = lane >> 5;
-    const uint32_t K = L + 2;
-    const int64_t pz = (int64_t)o - 1 + (int64_t)w;
-    const bool exists = w < K && pz >= 0 && (uint64_t)pz < n;
-    uint32_t code = 0;
-    if (exists) {
-        const uint8_t b = reverse ? s[n - 1 - (uint64_t)pz] : s[pz];
-        code = reverse ? sgc_base_code_rc(b) : sgc_base_code(b);
-    }
-    const uint32_t b0 = (uint32_t)(__ballot(exists && code < 4 && (code & 1u)) >> (32 * half));
-    const uint32_t b1 = (uint32_t)(__ballot(exists && code < 4 && (code & 2u)) >> (32 * half));
-    const uint32_t isn = (uint32_t)(__ballot(exists && code == 4) >> (32 * half));
-    const uint32_t bad = (uint32_t)(__ballot(exists && code == 5) >> (32 * half));
-    const bool c_ok = (uint64_t)o + L <= n;
-    const bool p_ok = c_ok && recursion && ((uint64_t)o + 1 + L <= n);
-    const bool m_ok = p_ok && o >= 1;
-    span = c_ok ? (spread_bits(b0) | (spread_bits(b1) << 1)) : 0;
-    const uint32_t wmask = L >= 32 ? 0xFFFFFFFFu : ((1u << L) - 1u);
-    const bool ok[3] = {m_ok, c_ok, p_ok};
-    uint32_t st[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const uint32_t inv = ((isn | bad) >> k) & wmask, nn = (isn >> k) & wmask, bb = (bad >> k) & wmask;
-        const uint32_t cnt = __popc(inv);
-        if (!ok[k] || !c_ok || cnt >= 2 || bb) st[k] = SGC_STATE_DEAD;
-        else if (cnt == 0) st[k] = SGC_STATE_CLEAN;
-        else st[k] = 2u + (uint32_t)(__ffs(nn) - 1);
-    }
-    status = (uint64_t)st[1] + (uint64_t)K * ((uint64_t)st[2] + (uint64_t)K * (uint64_t)st[0]);
-}
-
 __global__ void __launch_bounds__(FQ_THREADS) k_fastq_count(const uint8_t *__restrict__ text, uint64_t n,
                                                             uint32_t *__restrict__ tile_nl) {
     __shared__ uint32_t wsum[FQ_THREADS / 64];
@@ -108,7 +65,7 @@ __global__ void __launch_bounds__(FQ_THREADS) k_fastq_count(const uint8_t *__res
     const uint64_t tile0 = (uint64_t)blockIdx.x * FQ_TILE;
     uint32_t c = 0;
 #pragma unroll
-    for (uint32_t s = 0; s < FQ_SUB; s++) {                 // 16 B per lane per load: fully coalesced
+    for (uint32_t s = 0; s < FQ_TILE / (FQ_THREADS * 16u); s++) {      // 16 B per lane per load: fully coalesced
         const uint64_t base = tile0 + ((uint64_t)s * FQ_THREADS + t) * 16;
         if (base < n) c += __popc(nl_mask16(text, base, n, nullptr));
     }
@@ -143,121 +100,201 @@ __global__ void __launch_bounds__(1024) k_scan_tiles(uint32_t *__restrict__ v, u
     if (t == 1023) v[n] = part[1023];
 }
 
-#define FQ_LIST 1024u                       // sequence lines found per sub-tile (<= one per 16-byte piece)
-template <bool REC16>
-__global__ void __launch_bounds__(FQ_THREADS) k_fastq_pack(const uint8_t *__restrict__ text, uint64_t n,
-                                                           const uint32_t *__restrict__ tile_base, uint32_t L,
-                                                           int reverse, uint32_t o, int recursion,
-                                                           uint64_t *__restrict__ recs, uint32_t dbg) {
-    __shared__ __attribute__((aligned(16))) uint8_t stage[FQ_TILE];   // the whole tile, filled sub-tile by sub-tile
-    __shared__ __attribute__((aligned(8))) uint16_t masks[FQ_TILE / 16];   // newline mask of every 16-byte piece
-    __shared__ uint32_t wsum[FQ_THREADS / 64];
-    __shared__ uint32_t l_q[FQ_LIST], l_line[FQ_LIST], n_list;   // newline offset in the tile, global line index
-    const uint32_t t = threadIdx.x, lane = t & 63u;
-    const uint64_t tile0 = (uint64_t)blockIdx.x * FQ_TILE;
-    const uint64_t *masks64 = reinterpret_cast<const uint64_t *>(masks);
-    uint32_t carry = tile_base[blockIdx.x];                 // lines completed before the current sub-tile
-    for (uint32_t s = 0; s < FQ_SUB; s++) {
-        const uint32_t piece = s * FQ_THREADS + t;
-        const uint64_t base = tile0 + (uint64_t)piece * 16;
-        const uint32_t m = base < n ? nl_mask16(text, base, n, stage + piece * 16) : 0;
-        const uint32_t c = __popc(m);
-        masks[piece] = (uint16_t)m;
-        if (t == 0) n_list = 0;
-        uint32_t incl = c;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t v = __shfl_up(incl, off, 64);
-            if ((int)lane >= off) incl += v;
-        }
-        if (lane == 63) wsum[t >> 6] = incl;
-        __syncthreads();
-        uint32_t before = incl - c, total = 0;
-        for (uint32_t w = 0; w < FQ_THREADS / 64; w++) {
-            if (w < (t >> 6)) before += wsum[w];
-            total += wsum[w];
-        }
-        // every newline that ends a SEQUENCE line (line % 4 == 1) goes to the list; at most one per piece can be
-        // missed only if a piece held two of them, which needs a record shorter than 16 bytes: handled inline
-        uint32_t line = carry + before;                      // global index of the line ended by my first newline
-        uint32_t mm = m, mine = 0xFFFFFFFFu;
-        while (mm) {
-            const uint32_t k = __ffs(mm) - 1;
-            mm &= mm - 1;
-            if ((line & 3u) == 1u) {
-                if (mine == 0xFFFFFFFFu) mine = (k << 28) | 0;   // placeholder, filled below
-                const uint32_t at = atomicAdd(&n_list, 1u);
-                l_q[at] = piece * 16 + k;
-                l_line[at] = line;
-            }
-            line++;
-        }
-        __syncthreads();
-        // one half-wave per listed sequence line
-        const uint32_t nl = n_list;
-        for (uint32_t i0 = 0; i0 < nl; i0 += FQ_THREADS / 32) {
-            const uint32_t idx = i0 + (t >> 5);
-            const bool have = idx < nl;
-            const uint32_t qo = have ? l_q[idx] : 0;             // offset of the '\n' inside the tile
-            // start of the line: one past the previous newline.  Search the piece masks backwards, four pieces
-            // (one u64) at a time; if the tile holds none, the line began in an earlier tile: walk back in memory.
-            uint32_t po = 0;
-            bool in_tile = true;
-            if (have) {
-                const uint32_t pc = qo >> 4, kq = qo & 15u;
-                const uint32_t below = (uint32_t)masks[pc] & ((1u << kq) - 1u);
-                if (below) {
-                    po = pc * 16 + (31 - __clz(below)) + 1;
-                } else {
-                    // pieces [0, pc): first the remainder of pc's group of four, then whole groups
-                    int g = (int)(pc >> 2);
-                    uint64_t word = masks64[g] & ((1ull << (16 * (pc & 3u))) - 1ull);
-                    while (word == 0 && g > 0) word = masks64[--g];
-                    if (word) {
-                        const uint32_t hb = 63 - __clzll((long long)word);       // highest newline bit in the group
-                        po = (uint32_t)g * 64 + hb + 1;
-                    } else {
-                        in_tile = false;
-                    }
-                }
-            }
-            uint64_t span = 0, status = 0;
-            const uint64_t q = tile0 + qo;
-            if (in_tile) {
-                pack_coop(stage + po, have ? (uint64_t)(qo - po) : 0, L, reverse, o, recursion, span, status);
-            } else {
-                uint64_t p = tile0;
-                while (p > 0 && text[p - 1] != 0x0A) p--;
-                pack_coop(text + p, q - p, L, reverse, o, recursion, span, status);
-            }
-            if (have && (t & 31u) == 0) {
-                const uint64_t r = l_line[idx] >> 2;
-                if (REC16) { recs[2 * r] = span; recs[2 * r + 1] = status; }
-                else recs[r] = span | (status << (2 * (L + 2)));
-            }
-        }
-        carry += total;
-        __syncthreads();                                     // wsum / list are reused by the next sub-tile
+// lines j in [0, i) of the part with (ph + j) % 4 == 1, i.e. sequence lines before local line i
+__host__ __device__ __forceinline__ uint32_t seq_lines_before(uint32_t ph, uint32_t i) { return ((ph + i + 2u) >> 2) - ((ph + 2u) >> 2); }
+
+// first newline in stage-relative [a, b), or b
+__device__ __forceinline__ uint32_t find_nl_fwd(const uint64_t *m64, uint32_t a, uint32_t b) {
+    if (a >= b) return b;
+    uint32_t w = a >> 6;
+    uint64_t word = m64[w] & (~0ull << (a & 63u));
+    for (;;) {
+        if (word) { const uint32_t q = w * 64u + (uint32_t)__builtin_ctzll(word); return q < b ? q : b; }
+        w++;
+        if (w * 64u >= b) return b;
+        word = m64[w];
     }
-    (void)dbg;
+}
+// last newline in stage-relative [a, b), or 0xFFFFFFFF
+__device__ __forceinline__ uint32_t find_nl_bwd(const uint64_t *m64, uint32_t a, uint32_t b) {
+    if (a >= b) return 0xFFFFFFFFu;
+    uint32_t w = (b - 1u) >> 6;
+    uint64_t word = m64[w] & (~0ull >> (63u - ((b - 1u) & 63u)));
+    for (;;) {
+        if (word) { const uint32_t q = w * 64u + 63u - (uint32_t)__builtin_clzll(word); return q >= a ? q : 0xFFFFFFFFu; }
+        if (w * 64u <= a) return 0xFFFFFFFFu;
+        w--;
+        word = m64[w];
+    }
 }
 
-void sgc_launch_fastq(hipStream_t st, const uint8_t *text, uint64_t n, uint32_t *tile_scratch, uint32_t L, bool rec16,
-                      int reverse, uint32_t o, int recursion, uint64_t *recs) {
-    if (n == 0) return;
-    const uint32_t tiles = (uint32_t)((n + FQ_TILE - 1) / FQ_TILE);
-    hipLaunchKernelGGL(k_fastq_count, dim3(tiles), dim3(FQ_THREADS), 0, st, text, n, tile_scratch);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tile_scratch, tiles);
-    static const uint32_t dbg = getenv("SGC_FQ_DBG") ? (uint32_t)atoi(getenv("SGC_FQ_DBG")) : 0;   // timing ablations only
-    if (rec16)
-        hipLaunchKernelGGL((k_fastq_pack<true>), dim3(tiles), dim3(FQ_THREADS), 0, st, text, n, tile_scratch, L, reverse, o,
-                           recursion, recs, dbg);
-    else
-        hipLaunchKernelGGL((k_fastq_pack<false>), dim3(tiles), dim3(FQ_THREADS), 0, st, text, n, tile_scratch, L, reverse, o,
-                           recursion, recs, dbg);
+struct fq_args {
+    const uint8_t *text;          // the part: whole lines
+    uint64_t n;                   // its bytes
+    const uint32_t *tile_base;    // newlines before each tile; tile_base[tiles] = total
+    uint64_t first_line;          // global line number of the part's first line (only for error reports and the phase)
+    uint64_t *recs;               // record r of the part -> recs[r] (rec16: two words)
+    unsigned long long *err;      // err[0]: ~0 - (smallest 1-based number of a line whose marker byte is wrong), 0 = none; err[1]: flags
+    uint32_t tiles, expect_nl;    // expect_nl: newline count the host announced
+    uint32_t n_lines;             // lines of the part as the host counts them (newlines + an unterminated last line): recs[] holds
+                                  // exactly the sequence lines among them, and nothing beyond is ever written
+    uint32_t L, o, halo;          // halo: bytes staged beyond the tile, multiple of 64, <= FQ_HALO_MAX
+    int reverse, recursion;
+};
+
+template <bool REC16>
+__global__ void __launch_bounds__(FQ_THREADS) k_fastq_pack(const fq_args a) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[FQ_TILE + FQ_HALO_MAX];
+    __shared__ __attribute__((aligned(8))) uint16_t masks[FQ_PIECES];      // newline mask of every 16-byte piece
+    __shared__ uint32_t list[FQ_CAP], wtmp[17];
+    const uint32_t t = threadIdx.x, tile = blockIdx.x;
+    const uint64_t tile0 = (uint64_t)tile * FQ_TILE;
+    const uint32_t ph = (uint32_t)(a.first_line & 3u), cap = a.o + a.L + 2u;
+    // staged region: absolute [r0, r0 + HB + FQ_TILE + HF); HB bytes before the tile (reverse strand), HF after (forward)
+    const uint32_t HB = a.reverse ? (tile0 >= a.halo ? a.halo : 0u) : 0u, HF = a.reverse ? 0u : a.halo;
+    const uint64_t r0 = tile0 - HB;
+    const uint32_t span = HB + FQ_TILE + HF;
+    const uint32_t staged = (uint32_t)(a.n - r0 < span ? a.n - r0 : span);          // bytes that exist
+    const uint32_t n_pieces = span / 16u;
+    uint32_t mk[FQ_PIECES / FQ_THREADS + 1];
+#pragma unroll
+    for (uint32_t k = 0; k < FQ_PIECES / FQ_THREADS + 1; k++) {
+        const uint32_t piece = k * FQ_THREADS + t;
+        if (piece < n_pieces) {
+            const uint64_t base = r0 + (uint64_t)piece * 16;
+            mk[k] = base < a.n ? nl_mask16(a.text, base, a.n, stage + piece * 16) : 0u;
+        }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < FQ_PIECES / FQ_THREADS + 1; k++) {
+        const uint32_t piece = k * FQ_THREADS + t;
+        if (piece < n_pieces) masks[piece] = (uint16_t)mk[k];
+    }
+    __syncthreads();
+    const uint64_t *m64 = reinterpret_cast<const uint64_t *>(masks);
+    // lane t owns tile bytes [64 t, 64 t + 64)
+    const uint64_t mine = m64[(HB >> 6) + t];
+    uint32_t total;
+    const uint32_t before = wg_scan_1024((uint32_t)__popcll(mine), wtmp, &total);
+    const uint32_t l0 = a.tile_base[tile], l1 = l0 + total;          // local line numbers ended by this tile's newlines
+    if (tile == 0 && t == 0) {
+        if (a.tile_base[a.tiles] != a.expect_nl) atomicOr(&a.err[1], 1ull);
+        // marker byte of the part's first line
+        const uint8_t c = stage[HB];
+        if ((ph == 0 && c != '@') || (ph == 2 && c != '+')) atomicMax(&a.err[0], ~0ull - ((unsigned long long)a.first_line + 1ull));
+    }
+    // the sequence lines this tile owns: [rlo, rhi) as record numbers of the part
+    const uint32_t n_lines = a.n_lines;
+    uint32_t rlo, rhi;
+    if (a.reverse) {
+        rlo = seq_lines_before(ph, l0 < n_lines ? l0 : n_lines);
+        rhi = seq_lines_before(ph, l1 < n_lines ? l1 : n_lines);
+    } else {
+        rlo = tile == 0 ? 0u : seq_lines_before(ph, l0 + 1u < n_lines ? l0 + 1u : n_lines);
+        rhi = seq_lines_before(ph, l1 + 1u < n_lines ? l1 + 1u : n_lines);
+    }
+    for (uint32_t rb = rlo; rb < rhi || rb == rlo; rb += FQ_CAP) {
+        // list the owned sequence lines [rb, rb + FQ_CAP): forward = stage offset of the line start, reverse = of its '\n'
+        uint64_t mm = mine;
+        uint32_t i = l0 + before;                       // local number of the line my next newline ends
+        while (mm) {
+            const uint32_t bit = (uint32_t)__builtin_ctzll(mm);
+            mm &= mm - 1;
+            const uint32_t pos = HB + 64u * t + bit;    // stage offset of the newline
+            const uint32_t phase = (ph + i) & 3u;
+            if (rb == rlo) {
+                // marker byte of the next line (lines 4k start with '@', lines 4k + 2 with '+')
+                const uint64_t nxt = r0 + pos + 1u;
+                if (nxt < a.n && (phase == 3u || phase == 1u)) {
+                    const uint8_t c = pos + 1u < staged ? stage[pos + 1u] : a.text[nxt];
+                    if (c != (phase == 3u ? '@' : '+')) atomicMax(&a.err[0], ~0ull - ((unsigned long long)a.first_line + i + 2ull));
+                }
+            }
+            if (a.reverse) {
+                if (phase == 1u) { const uint32_t r = seq_lines_before(ph, i); if (r - rb < FQ_CAP) list[r - rb] = pos; }
+            } else if (phase == 0u && r0 + pos + 1u < a.n) {
+                const uint32_t r = seq_lines_before(ph, i + 1u);
+                if (r - rb < FQ_CAP) list[r - rb] = pos + 1u;
+            }
+            i++;
+        }
+        if (!a.reverse && tile == 0 && t == 0 && ph == 1u && rb == 0 && staged) list[0] = HB;    // the part starts with a sequence line
+        __syncthreads();
+        const uint32_t nrec = rhi - rb < FQ_CAP ? rhi - rb : FQ_CAP;
+        if (t < nrec) {
+            const uint8_t *s; uint64_t len;
+            if (!a.reverse) {
+                const uint32_t st = list[t];
+                const uint32_t lim = st + cap < staged ? st + cap : staged;
+                const uint32_t q = find_nl_fwd(m64, st, lim);
+                s = stage + st;
+                if (q < lim || (lim == staged && r0 + staged == a.n)) {      // the line ends at q (a newline, or the end of the part)
+                    len = q - st;
+                    if (len && stage[q - 1] == 0x0D) len--;
+                } else if (lim - st == cap) {
+                    len = cap;                                               // at least cap bytes: every window is in bounds
+                } else {
+                    // the halo is too short for this offset: walk the line in global memory
+                    const uint64_t g0 = r0 + st;
+                    uint64_t g = g0;
+                    while (g < a.n && g - g0 < cap && a.text[g] != 0x0A) g++;
+                    len = g - g0;
+                    if (len && len < cap && a.text[g - 1] == 0x0D) len--;
+                    s = a.text + g0;
+                }
+            } else {
+                uint32_t e = list[t];                                        // the '\n' ending the sequence line
+                if (e && stage[e - 1] == 0x0D) e--;
+                const uint32_t lo = e > cap ? e - cap : 0u;
+                const uint32_t p = find_nl_bwd(m64, lo, e);
+                if (p != 0xFFFFFFFFu) { s = stage + p + 1u; len = e - (p + 1u); }
+                else if (e - lo == cap) { s = stage + lo; len = cap; }      // only the last cap bytes are ever addressed
+                else if (r0 == 0) { s = stage; len = e; }                    // the line starts the part
+                else {
+                    const uint64_t ge = r0 + e;
+                    uint64_t g = ge;
+                    while (g > 0 && ge - g < cap && a.text[g - 1] != 0x0A) g--;
+                    s = a.text + g; len = ge - g;
+                }
+            }
+            uint64_t spn, sts;
+            sgc_pack_one(s, len, a.L, a.reverse, a.o, a.recursion, spn, sts);
+            const uint64_t r = (uint64_t)rb + t;
+            if (REC16) { a.recs[2 * r] = spn; a.recs[2 * r + 1] = sts; }
+            else a.recs[r] = spn | (sts << (2 * (a.L + 2)));
+        }
+        if (rhi - rb <= FQ_CAP) break;
+        __syncthreads();                                 // list[] is rewritten by the next round
+    }
 }
 
 uint32_t sgc_fastq_tiles(uint64_t n) { return (uint32_t)((n + FQ_TILE - 1) / FQ_TILE); }
+
+uint64_t sgc_fastq_records(uint64_t first_line, uint64_t n_lines) {
+    const uint64_t ph = first_line & 3u;
+    return ((ph + n_lines + 2u) >> 2) - ((ph + 2u) >> 2);
+}
+
+void sgc_launch_fastq_count(hipStream_t st, const uint8_t *text, uint64_t n, uint32_t *tile_scratch) {
+    if (n == 0) return;
+    const uint32_t tiles = sgc_fastq_tiles(n);
+    hipLaunchKernelGGL(k_fastq_count, dim3(tiles), dim3(FQ_THREADS), 0, st, text, n, tile_scratch);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, st, tile_scratch, tiles);
+}
+
+void sgc_launch_fastq_pack(hipStream_t st, const uint8_t *text, uint64_t n, const uint32_t *tile_scratch, uint64_t first_line,
+                           uint32_t expect_nl, uint32_t n_lines, uint32_t L, bool rec16, int reverse, uint32_t o, int recursion, uint64_t *recs,
+                           unsigned long long *err) {
+    if (n == 0) return;
+    fq_args a;
+    a.text = text; a.n = n; a.tile_base = tile_scratch; a.first_line = first_line; a.recs = recs; a.err = err;
+    a.tiles = sgc_fastq_tiles(n); a.expect_nl = expect_nl; a.n_lines = n_lines; a.L = L; a.o = o;
+    const uint64_t want = ((uint64_t)o + L + 2u + 63u) & ~63ull;
+    a.halo = (uint32_t)(want < FQ_HALO_MAX ? want : FQ_HALO_MAX);
+    a.reverse = reverse; a.recursion = recursion;
+    if (rec16) hipLaunchKernelGGL((k_fastq_pack<true>), dim3(a.tiles), dim3(FQ_THREADS), 0, st, a);
+    else hipLaunchKernelGGL((k_fastq_pack<false>), dim3(a.tiles), dim3(FQ_THREADS), 0, st, a);
+}
 
 // ------------------------------------------------------------------------------------------------
 // raw reads (bytes + offsets) -> records.  A workgroup owns PR_READS consecutive reads; their bytes are one
@@ -290,8 +327,7 @@ __global__ void __launch_bounds__(PR_THREADS) k_pack_reads_lds(const uint8_t *__
         }
     }
     __syncthreads();
-    // one lane per read: here every lane has work (unlike the FASTQ kernel, where a sequence line ends in only
-    // one of ~20 lanes' pieces), so the serial per-lane packer keeps all lanes busy
+    // one lane per read: every lane has work, so the serial per-lane packer keeps all lanes busy
     const uint64_t i = i0 + t;
     if (i >= i1) return;
     const uint64_t b = offsets[i], e = offsets[i + 1];

@@ -81,9 +81,14 @@ int sgc_device_build_permute(hipStream_t st, const uint64_t *d_keys, uint32_t n,
                              uint32_t bloom_log2, uint64_t *d_amb, unsigned long long *d_entries, void *d_scratch);
 
 // ---- FASTQ ingest (sgc_fastq.hip) -----------------------------------------------------------------
-// tile_scratch: sgc_fastq_tiles(n) + 1 u32; after the call tile_scratch[tiles] = number of '\n' in the text
+// tile_scratch: sgc_fastq_tiles(n) + 1 u32.  sgc_launch_fastq_count leaves the newlines before every tile there and
+// tile_scratch[tiles] = number of '\n' in the text; sgc_launch_fastq_pack then writes the records of the part's
+// sequence lines (sgc_fastq_records(first_line, n_lines) of them) and reports marker-byte errors through err[2].
 uint32_t sgc_fastq_tiles(uint64_t n);
-void sgc_launch_fastq(hipStream_t st, const uint8_t *text, uint64_t n, uint32_t *tile_scratch, uint32_t L, bool rec16,
-                      int reverse, uint32_t o, int recursion, uint64_t *recs);
+uint64_t sgc_fastq_records(uint64_t first_line, uint64_t n_lines);
+void sgc_launch_fastq_count(hipStream_t st, const uint8_t *text, uint64_t n, uint32_t *tile_scratch);
+void sgc_launch_fastq_pack(hipStream_t st, const uint8_t *text, uint64_t n, const uint32_t *tile_scratch, uint64_t first_line,
+                           uint32_t expect_nl, uint32_t n_lines, uint32_t L, bool rec16, int reverse, uint32_t o, int recursion,
+                           uint64_t *recs, unsigned long long *err);
 void sgc_launch_pack_reads_lds(hipStream_t st, const uint8_t *seqs, const uint64_t *offsets, uint64_t n, uint32_t L,
                                bool rec16, int reverse, uint32_t o, int recursion, uint64_t *recs);

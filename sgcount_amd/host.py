@@ -72,6 +72,7 @@ def parse_fastx(text: bytes):
     lines = text.split(b"\n")
     if lines and lines[-1] == b"":
         lines.pop()
+    lines = [ln[:-1] if ln.endswith(b"\r") else ln for ln in lines]      # CRLF: '\r' belongs to the terminator (unpinned upstream)
     if text[:1] == b">":
         step, marker = 2, b">"
     elif text[:1] == b"@":
@@ -148,12 +149,13 @@ class Library:
         return len(self._order)
 
     # -- device residency ------------------------------------------------------------------
-    def device(self, one_mismatch: bool, device_index: int = 0):
-        """The resident (library [+ permute]) tables for this library on one GPU."""
+    def device(self, one_mismatch: bool, device_index: int = 0, options=None):
+        """The resident (library [+ permute]) tables for this library on one GPU.  options: sgc_set_option pairs applied
+        before the tables are built (first call only)."""
         key = (bool(one_mismatch), device_index)
         dl = self._devices.get(key)
         if dl is None:
-            dl = DeviceLibrary(self, one_mismatch, device_index)
+            dl = DeviceLibrary(self, one_mismatch, device_index, options)
             self._devices[key] = dl
         return dl
 
@@ -161,13 +163,15 @@ class Library:
 class DeviceLibrary:
     """sgc_ctx + sgc_set_library: what (&Library, &Option<Permuter>) is to Counter::new."""
 
-    def __init__(self, library: Library, one_mismatch: bool, device_index: int = 0):
+    def __init__(self, library: Library, one_mismatch: bool, device_index: int = 0, options=None):
         self.lib = _ffi.load()
         self.library = library
         self.one_mismatch = bool(one_mismatch)
         self.ctx = C.c_void_p()
         _ffi.check(self.lib.sgc_init(device_index, C.byref(self.ctx)))
         self._fin = weakref.finalize(self, self.lib.sgc_free, self.ctx)
+        for k, v in (options or {}).items():
+            _ffi.check(self.lib.sgc_set_option(self.ctx, k.encode(), int(v)))
         flat = b"".join(library.keys())
         try:
             _ffi.check(self.lib.sgc_set_library(self.ctx, flat, len(library), library.size(), int(one_mismatch)))

@@ -27,7 +27,7 @@ def load():
         L.sgh_last_error.restype = C.c_char_p
         for name in ("sgh_cli", "sgh_entropy_offset_group", "sgh_positional_entropy", "sgh_minimize_mse",
                      "sgh_generate_sample_names", "sgh_genemap_get", "sgh_genemap_missing", "sgh_generate_columns",
-                     "sgh_format_results", "sgh_library_info", "sgh_fastx_stats", "sgh_fastq_chunk_cut"):
+                     "sgh_format_results", "sgh_library_info", "sgh_fastx_stats", "sgh_text_feeder_walk"):
             getattr(L, name).restype = C.c_int
         _lib = L
     return _lib
@@ -117,11 +117,14 @@ def fastx_stats(path):
     return a.value, b.value, c.value
 
 
-def fastq_chunk_cut(buf: bytes, eof: bool):
-    """Bytes of `buf` that form whole 4-line FASTQ records (the text path's chunk cutter)."""
-    out = C.c_uint64()
-    _chk(load().sgh_fastq_chunk_cut(buf, len(buf), int(eof), C.byref(out)))
-    return out.value
+def text_feeder_walk(path, slice_bytes=1 << 16, threads=3):
+    """Walks a file through the text path's byte source (TextFeeder) exactly as count() does and returns
+    (parts, bytes, lines, fnv1a-64 of all pushed bytes, first byte, is_gz)."""
+    parts, nbytes, lines, fnv = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+    fb, gz = C.c_int(), C.c_int()
+    _chk(load().sgh_text_feeder_walk(path.encode(), C.c_uint64(slice_bytes), C.c_uint64(threads), C.byref(parts), C.byref(nbytes),
+                                     C.byref(lines), C.byref(fnv), C.byref(fb), C.byref(gz)))
+    return parts.value, nbytes.value, lines.value, fnv.value, fb.value, bool(gz.value)
 
 
 def cli(argv):

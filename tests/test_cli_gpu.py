@@ -128,3 +128,36 @@ def test_python_count_wrapper(tmp_path, example_library_text, example_reads):
     with pytest.raises(hostlib.HostError) as e:
         hostlib.count(LIB, [os.path.join(str(tmp_path), "missing.fq")], offset=5)
     assert e.value.code == 101
+
+
+def test_stats_json_and_plain_text_pipeline(cli, tmp_path, example_library_text, example_reads):
+    """The streaming text path on a plain (uncompressed) file with tiny slices and several reader threads: same table
+    as the oracle, and --stats-json reports the stages."""
+    import json
+    text = example_reads["diff.sequence"]
+    fq = os.path.join(str(tmp_path), "diff.fastq")
+    open(fq, "wb").write(text)
+    stats = os.path.join(str(tmp_path), "stats.json")
+    rc, out, err = run(cli, "-l", LIB, "-i", fq, "-a", "5", "-q", "--io-threads", "3", "--chunk-mb", "0", "--stats-json", stats)
+    assert rc == 0, err
+    assert out == oracle_table(example_library_text, [text], ["diff"], [(False, 5)], False, True)
+    st = json.load(open(stats))
+    s0 = st["samples"][0]
+    assert s0["text_path"] and not s0["gz"] and s0["reads"] == 1101 and s0["reader_threads"] == 3
+    assert s0["text_bytes"] == len(text) and st["total_s"] > 0 and s0["ingest_kernels_ms"] > 0 and s0["count_kernels_ms"] > 0
+
+
+def test_malformed_fastq_panics_like_the_reference(cli, tmp_path, example_reads):
+    """fxread panics on a malformed record (unpinned): exit code 101, on the text path (GPU-verified marker
+    bytes) and on the record-reader path alike; a truncated last record too."""
+    text = example_reads["sequence"]
+    lines = text.split(b"\n")
+    bad = list(lines)
+    bad[4 * 500 + 2] = b"-"                         # separator line without '+'
+    for name, body in (("bad_plus.fastq", b"\n".join(bad)), ("trunc.fastq", b"\n".join(lines[: 4 * 700 + 2]) + b"\n")):
+        p = os.path.join(str(tmp_path), name)
+        open(p, "wb").write(body)
+        for pack in ("fastq", "device"):
+            rc, out, err = run(cli, "-l", LIB, "-i", p, "-a", "5", "-q", "--pack", pack)
+            assert rc == 101, (name, pack, rc, err)
+            assert "panicked" in err

@@ -168,46 +168,42 @@ def test_results_match_oracle(H, tmp_path):
     assert e.value.code == 101
 
 
-def test_fastq_chunk_cut_matches_line_walk():
-    """The text path cuts chunks with a vectorised newline count + memrchr; a plain line walk must agree, on
-    texts whose quality lines hold '@' and '+', with and without a trailing newline, cut anywhere."""
+def test_text_feeder_delivers_every_byte_once(tmp_path):
+    """The byte source of the count path's text mode (multi-threaded pread / one inflating producer, slices cut at
+    their last newline, the rest carried): every byte is delivered exactly once and in order, the per-slice newline
+    counts are right, whatever the slice size and thread count — plain and .gz, with and without a final newline,
+    with lines longer than a slice."""
+    import gzip
     import random
     from sgcount_amd import hostlib
     rng = random.Random(31)
     recs = []
-    for i in range(300):
-        n = rng.randrange(0, 90)
+    for i in range(3000):
+        n = rng.choice([0, 1, 20, 90, 150, 400])
         seq = bytes(rng.choice(b"ACGTN") for _ in range(n))
         qual = bytes(rng.choice(b"@+I#5") for _ in range(n))
         recs.append(b"@r%d\n%s\n+\n%s\n" % (i, seq, qual))
+    recs.append(b"@long\n" + b"A" * 200_000 + b"\n+\n" + b"I" * 200_000 + b"\n")       # lines longer than a 64 KiB slice
     text = b"".join(recs)
 
-    def walk(buf):
-        lines, cut, pos = 0, 0, 0
-        while True:
-            nl = buf.find(b"\n", pos)
-            if nl < 0:
-                break
-            lines += 1
-            pos = nl + 1
-            if lines % 4 == 0:
-                cut = pos
-        return cut
-    for _ in range(400):
-        end = rng.randrange(1, len(text) + 1)
-        buf = text[:end]
-        want = walk(buf)
-        if want == 0:
-            with pytest.raises(hostlib.HostError):
-                hostlib.fastq_chunk_cut(buf, False)
-        else:
-            assert hostlib.fastq_chunk_cut(buf, False) == want
-    # final chunk: whole records pass with or without the last newline, a torn record is a panic (code 101)
-    assert hostlib.fastq_chunk_cut(text, True) == len(text)
-    assert hostlib.fastq_chunk_cut(text[:-1], True) == len(text) - 1
-    with pytest.raises(hostlib.HostError) as e:
-        hostlib.fastq_chunk_cut(text[: len(text) - len(recs[-1]) + 5], True)
-    assert e.value.code == 101
-    # long runs: the 8-bit lane accumulators of the newline counter are flushed before they can wrap
-    big = b"\n" * (255 * 64 * 3 + 17) + b"x"
-    assert hostlib.fastq_chunk_cut(big, False) == (255 * 64 * 3 + 17) // 4 * 4
+    def fnv(b):
+        h = 1469598103934665603
+        for c in b:
+            h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+    for body in (text, text[:-1]):
+        want_lines = body.count(b"\n") + (0 if body.endswith(b"\n") else 1)
+        want = (len(body), want_lines, fnv(body))
+        plain = tmp_path / "t.fastq"
+        plain.write_bytes(body)
+        gz = tmp_path / "t.fastq.gz"
+        with gzip.open(gz, "wb", compresslevel=1) as f:
+            f.write(body)
+        for path, is_gz in ((plain, False), (gz, True)):
+            for slice_bytes, threads in ((1 << 16, 1), (1 << 16, 3), (100_000, 4), (1 << 22, 2)):
+                parts, nbytes, lines, h, first, gzflag = hostlib.text_feeder_walk(str(path), slice_bytes, threads)
+                assert (nbytes, lines, h) == want and first == ord("@") and gzflag == is_gz
+                assert parts >= 1
+    empty = tmp_path / "empty.fastq"
+    empty.write_bytes(b"")
+    assert hostlib.text_feeder_walk(str(empty))[:3] == (0, 0, 0)

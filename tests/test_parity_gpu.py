@@ -199,9 +199,8 @@ def _random_case(rng, L, n_guides, n_reads, o):
 @pytest.mark.parametrize("variant", [4, 3])
 @pytest.mark.parametrize("L,n_guides", [(20, 2000), (12, 300), (23, 500), (27, 400)])
 @pytest.mark.parametrize("reverse", [False, True])
-def test_random_vs_oracle(S, L, n_guides, reverse, variant, monkeypatch):
+def test_random_vs_oracle(S, L, n_guides, reverse, variant):
     """variant 4 = in-LDS core resolver (the default), 3 = probing resolver; both must give the oracle's table"""
-    monkeypatch.setenv("SGC_VARIANT", str(variant))
     rng = random.Random(1000 * L + n_guides + reverse)
     o = 9
     guides, reads = _random_case(rng, L, n_guides, 20000, o)
@@ -213,6 +212,7 @@ def test_random_vs_oracle(S, L, n_guides, reverse, variant, monkeypatch):
     perm = S.Permuter.new(lib.keys())
     off = S.Offset.Reverse(o) if reverse else S.Offset.Forward(o)
     for exact in (False, True):
+        lib.device(not exact).set_option("variant", variant)
         for recursion in (True, False):
             want, tot, mat = O.count_text(lib_text, reads_text, reverse, o, exact, recursion)
             for pack in ("host", "device"):
@@ -264,7 +264,7 @@ def _dense_case(rng, L, o):
 
 
 @pytest.mark.parametrize("L", [20, 23, 9, 6, 4])
-def test_dense_neighbourhoods_vs_oracle(S, L, monkeypatch):
+def test_dense_neighbourhoods_vs_oracle(S, L):
     """Every substitution and every 'N' of whole guide families, at all three alignments: the in-LDS core
     resolver (variant 4), the probing resolver (variant 3) and the oracle agree read for read in aggregate."""
     rng = random.Random(77 + L)
@@ -274,8 +274,8 @@ def test_dense_neighbourhoods_vs_oracle(S, L, monkeypatch):
     for recursion in (True, False):
         want, tot, mat = O.count_text(lib_text, reads_text, False, o, False, recursion)
         for variant in (4, 3):
-            monkeypatch.setenv("SGC_VARIANT", str(variant))
             lib = _lib(S, lib_text)
+            lib.device(True).set_option("variant", variant)
             perm = S.Permuter.new(lib.keys())
             ctr = S.Counter.new(S.parse_fastx(reads_text), lib, perm, S.Offset.Forward(o), L, recursion, pack="device")
             assert ctr.guide_counts().tolist() == want, (variant, recursion)
@@ -310,7 +310,7 @@ def test_core_index_overflow_falls_back(S):
     assert other.device(True).info().core_partitions >= 1
 
 
-def test_device_build_matches_host_build(S, monkeypatch):
+def test_device_build_matches_host_build(S):
     """The single-mismatch table built on the GPU (children -> rocPRIM sort -> CAS inserts, sgc_build.hip) answers
     every probe like the host-built one (sgc_tables.cpp) and like the oracle's Permuter, and holds as many entries."""
     rng = random.Random(2024)
@@ -334,10 +334,8 @@ def test_device_build_matches_host_build(S, monkeypatch):
         want.append(index[parent] if parent is not None else -1)
     got, entries = {}, {}
     for mode in ("device", "host"):
-        if mode == "host":
-            monkeypatch.setenv("SGC_HOST_BUILD", "1")
         lib = _lib(S, lib_text)
-        dev = lib.device(True)
+        dev = lib.device(True, options={"host_build": int(mode == "host")})
         out = dev.lookup(probes, which=1).tolist()
         got[mode] = [(-1 if w in index else v) for w, v in zip(probes, out)]     # children that are guides are unreachable
         entries[mode] = dev.info().perm_entries

@@ -251,6 +251,53 @@ def test_full_size_properties(env):
     wl.close()
 
 
+@pytest.mark.parametrize("exact,mode", [(True, 0), (False, 1), (True, 1)])
+def test_full_size_other_configs(env, exact, mode, tmp_path):
+    """BASELINE.json configs[1] (-x) and configs[3] (variable adapter, auto offset) at their full size — 100k guides,
+    100M reads: totals, count-sum invariant, linearity over a split, agreement of the generic kernels (variant 1) with
+    the shipped path, the offsetter's answer on the sample's own text (STAGGER: Forward(30), offsetter.rs:185-210),
+    and the oracle on a 1.5M-read prefix."""
+    import os
+    torch, S, synth, workload = env
+    ffi = S._ffi
+    from sgcount_amd import hostlib
+    n, ng = 100_000_000, 100_000
+    wl = workload.DeviceWorkload(n, ng, 20, one_mismatch=not exact, mode=mode)
+    lib_text = synth.library_fasta(wl.lib_seqs)
+    if mode == synth.MODE_STAGGER:
+        lp, rp = os.path.join(str(tmp_path), "lib.fa"), os.path.join(str(tmp_path), "head.fq")
+        open(lp, "wb").write(lib_text)
+        open(rp, "wb").write(synth.fastq_host(wl.lib_seqs, 0, 6000, mode=mode))
+        assert hostlib.entropy_offset_group(lp, [rp]) == [(False, 30)]
+    wl.step()
+    counts, total, matched = wl.result()
+    assert total == n and int(counts.sum()) == matched
+    # FIXED: 85 % exact + 2 + 2 % shifted (+ 5 + 1 % with one mismatch); STAGGER loses the 28/32-base prefixes (10 %)
+    lo, hi = {(True, 0): (0.885, 0.895), (False, 1): (0.84, 0.87), (True, 1): (0.78, 0.82)}[(exact, mode)]
+    assert lo < matched / total < hi, matched / total
+    ffi.check(wl.abi.sgc_sample_reset(wl.sample))
+    cut = 61_000_003
+    for first, m in ((0, cut), (cut, n - cut)):
+        ffi.check(wl.abi.sgc_sample_push_packed(wl.sample, wl.records.data_ptr() + 8 * first, m, ffi.MEM_DEVICE))
+    ffi.check(wl.abi.sgc_sample_export_device(wl.sample, wl.export.data_ptr()))
+    c2, t2, m2 = wl.result()
+    assert t2 == total and m2 == matched and np.array_equal(c2, counts)
+    wl.dl.set_option("variant", 1)
+    wl.step()
+    c1, t1, m1 = wl.result()
+    assert t1 == total and m1 == matched and np.array_equal(c1, counts)
+    wl.dl.set_option("variant", 4)
+    m = 1_500_000
+    wl.step(0, m)
+    cp, tp, mp = wl.result()
+    lib = O.Library(lib_text)
+    ctr = O.Counter(lib, None if exact else O.Permuter(lib), False, 30, 20, True)
+    for first in range(0, m, 500_000):
+        ctr.feed_text(synth.fastq_host(wl.lib_seqs, first, 500_000, mode=mode))
+    assert (cp.tolist(), tp, mp) == (ctr.table(), ctr.total_reads(), ctr.matched_reads())
+    wl.close()
+
+
 def test_extreme_skew(env):
     """Adversarial input: 40M reads of which 30M are ONE guide (one slice, one slot), 6M a single one-mismatch
     variant of another guide, 4M one junk read.  Exercises K1's multi-block spills, K2's list overflow/rescan
