@@ -17,6 +17,7 @@
 #include "../../include/sgcount_hip.h"
 #include "sgc_format.h"
 #include "sgc_kernels.h"
+#include "sgc_runs.h"
 #include "sgc_tables.h"
 
 static thread_local std::string g_err;
@@ -51,6 +52,7 @@ struct sgc_ctx {
     uint64_t *d_core_ents[2] = {nullptr, nullptr}, *d_amb = nullptr;
     uint32_t *d_core_gids[2] = {nullptr, nullptr};
     uint16_t *d_core_starts[2] = {nullptr, nullptr};
+    uint32_t *d_core_filt = nullptr;
     sgc_core_view v_core[2] = {};
     void *d_cbuf = nullptr; size_t cbuf_cap = 0;        // two record buffers of the core passes
     void *d_csmall = nullptr; size_t csmall_cap = 0;    // their histograms / partition starts / extents
@@ -77,6 +79,7 @@ struct sgc_ctx {
     uint32_t dbg = 0;           // timing-only ablation flags (results are wrong when non-zero)
     uint32_t k1_wgs = 256;      // workgroups of the partition kernel: few, so that few half-empty blocks are left open
     uint64_t max_chunk = 1ull << 27;   // records per internal pass (bounds the scratch buffers)
+    bool rest_filter = true;           // core pass A settles "no parent inside the core" with the rest filter (sgc_format.h)
     bool host_build = false;           // build the single-mismatch table on the host (sgc_tables.cpp) instead of the GPU
     uint32_t perm_bloom_bits = 8;      // Bloom bits per child of the single-mismatch filter
     // timing
@@ -177,25 +180,31 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
             uint64_t *pool = (uint64_t *)c->d_pool;
             uint32_t *desc = (uint32_t *)c->d_desc;
             { timed t(c, T_PART); sgc_launch_part_k1(c->stream, p, chunk, c->L, c->v_lib, g, pool, desc); }
-            { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg); }
             if (c->variant >= 4 && c->one_mm && c->has_core) {
-                // everything K2 did not settle (its misses + the generic partition) is resolved in LDS
+                // everything the slice probe does not settle (its misses + the generic partition) is resolved in LDS by the
+                // two core passes; k_count_slices itself lays those records out as pass A's runs
                 sgc_core_geometry cg;
-                sgc_core_plan(chunk, c->v_core[0], c->v_core[1], &cg);
+                sgc_core_plan(chunk, c->v_core[0], c->v_core[1], sgc_part_k2_grid(g), &cg);
                 rc = ensure(&c->d_cbuf, &c->cbuf_cap, (size_t)cg.recs_bytes * 2);
                 if (rc) return rc;
                 rc = ensure(&c->d_csmall, &c->csmall_cap, cg.small_bytes);
                 if (rc) return rc;
-                timed t(c, T_MISS, true);
-                sgc_launch_core(c->stream, c->L, c->v_lib, c->v_perm, c->v_core[0], c->v_core[1], c->d_amb, cg, pool, desc,
-                                g.n_blocks, g.block_records, (uint64_t *)c->d_cbuf, (uint64_t *)c->d_cbuf + chunk,
-                                (char *)c->d_desc + g.desc_tail_off, c->d_csmall, s->d_c32, s->d_matched, c->dbg);
+                uint64_t *buf0 = (uint64_t *)c->d_cbuf, *buf1 = buf0 + chunk;
+                void *zeroed = (char *)c->d_desc + g.desc_tail_off;
+                const sgc_runs ra = sgc_core_runs_a(cg, c->v_core[0], c->L, buf0, zeroed, c->d_csmall);
+                { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg, &ra); }
+                // timing: miss_ms = core pass A (+ its epilogue), hist_ms = core pass B
+                { timed t(c, T_MISS, true); sgc_launch_core(c->stream, 0, c->L, c->v_lib, c->v_perm, c->v_core[0], c->v_core[1], c->d_amb, cg, buf0, buf1, pool,
+                                                            zeroed, c->d_csmall, s->d_c32, s->d_matched, c->dbg); }
+                { timed t(c, T_HIST, true); sgc_launch_core(c->stream, 1, c->L, c->v_lib, c->v_perm, c->v_core[0], c->v_core[1], c->d_amb, cg, buf0, buf1, pool,
+                                                            zeroed, c->d_csmall, s->d_c32, s->d_matched, c->dbg); }
                 HIP_TRY(hipGetLastError());
                 done += chunk;
                 s->since_fold += chunk;
                 if (done < n) { sgc_launch_fold(c->stream, s->d_c32, s->d_c64, c->n); s->since_fold = 0; }
                 continue;
             }
+            { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg, nullptr); }
             rc = ensure(&c->d_gids, &c->gids_cap, g.gids_bytes);                // one slot per pool record: every read may miss
             if (rc) return rc;
             rc = ensure(&c->d_aux, &c->aux_cap, ((size_t)g.n_segs + 1) * 4);
@@ -304,7 +313,8 @@ static void free_tables(sgc_ctx *c) {
         c->d_core_ents[k] = nullptr; c->d_core_gids[k] = nullptr; c->d_core_starts[k] = nullptr; c->v_core[k] = sgc_core_view{};
     }
     if (c->d_amb) hipFree(c->d_amb);
-    c->d_amb = nullptr; c->has_core = false;
+    if (c->d_core_filt) hipFree(c->d_core_filt);
+    c->d_amb = nullptr; c->d_core_filt = nullptr; c->has_core = false;
     c->b_lib = sgc_bloom_view{}; c->b_perm = sgc_bloom_view{};
     c->d_lib_slots = c->d_perm_slots = nullptr;
     c->d_lib_vals = c->d_perm_vals = nullptr;
@@ -367,6 +377,7 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
         if (value < 1 || value > (int64_t)0xF0000000ll) return fail(SGC_E_ARG, "max_chunk out of range");
         c->max_chunk = (uint64_t)value; return SGC_OK;
     }
+    if (!strcmp(key, "rest_filter")) { c->rest_filter = value != 0; return SGC_OK; }         // takes effect at the next sgc_set_library
     if (!strcmp(key, "host_build")) { c->host_build = value != 0; return SGC_OK; }          // takes effect at the next sgc_set_library
     if (!strcmp(key, "perm_bloom_bits")) {
         if (value < 1 || value > 64) return fail(SGC_E_ARG, "perm_bloom_bits must be 1..64");
@@ -473,6 +484,9 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
             sgc_host_core hc[2];
             if (sgc_build_core_index(keys, L, 2, ca, hc[0]) && sgc_build_core_index(keys, L, 2 + ca, L - 2 - ca, hc[1])) {
                 hipError_t e = hipSuccess;
+                std::vector<uint32_t> filt;
+                const uint32_t fl2 = sgc_rest_filter_log2(n);
+                if (c->rest_filter) sgc_build_rest_filter(keys, hc[0].cs, hc[0].cl, fl2, filt);
                 for (int k = 0; k < 2 && e == hipSuccess; k++) {
                     e = hipMalloc((void **)&c->d_core_ents[k], hc[k].ents.size() * 8);
                     if (e == hipSuccess) e = hipMalloc((void **)&c->d_core_gids[k], hc[k].gids.size() * 4);
@@ -480,7 +494,12 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
                     if (e == hipSuccess) e = hipMemcpyAsync(c->d_core_ents[k], hc[k].ents.data(), hc[k].ents.size() * 8, hipMemcpyHostToDevice, c->stream);
                     if (e == hipSuccess) e = hipMemcpyAsync(c->d_core_gids[k], hc[k].gids.data(), hc[k].gids.size() * 4, hipMemcpyHostToDevice, c->stream);
                     if (e == hipSuccess) e = hipMemcpyAsync(c->d_core_starts[k], hc[k].starts.data(), hc[k].starts.size() * 2, hipMemcpyHostToDevice, c->stream);
-                    c->v_core[k] = sgc_core_view{c->d_core_ents[k], c->d_core_gids[k], c->d_core_starts[k], hc[k].log2_p, hc[k].cs, hc[k].cl, 0};
+                    c->v_core[k] = sgc_core_view{c->d_core_ents[k], c->d_core_gids[k], c->d_core_starts[k], hc[k].log2_p, hc[k].cs, hc[k].cl, 0, nullptr};
+                }
+                if (e == hipSuccess && !filt.empty()) {
+                    e = hipMalloc((void **)&c->d_core_filt, filt.size() * 4);
+                    if (e == hipSuccess) e = hipMemcpyAsync(c->d_core_filt, filt.data(), filt.size() * 4, hipMemcpyHostToDevice, c->stream);
+                    c->v_core[0].filt = c->d_core_filt; c->v_core[0].filt_log2 = fl2;
                 }
                 if (e == hipSuccess && !device_build) {
                     e = hipMalloc((void **)&c->d_amb, amb.size() * 8);
@@ -516,6 +535,7 @@ int sgc_library_info(sgc_ctx *c, sgc_lib_info *out) {
         out->core_partitions = 1ull << c->v_core[0].log2_p;
         for (int k = 0; k < 2; k++)
             out->table_bytes += ((uint64_t)SGC_CORE_EMAX * 12 + SGC_CORE_STARTS * 2) << c->v_core[k].log2_p;
+        if (c->d_core_filt) out->table_bytes += (uint64_t)3 << (c->v_core[0].filt_log2 - 3);
         out->table_bytes += (uint64_t)c->n * 16;
     }
     return SGC_OK;

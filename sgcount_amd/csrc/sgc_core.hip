@@ -27,9 +27,8 @@
 //   record goes on to pass B, which sees everything pass A could not, plus every exact level again.  The
 //   rare "1mm found at P/M in pass A, C-1mm undecided" case is closed on the spot with the global tables.
 //
-// Kernels: k_cp_count / k_cp_scatter (counting partition of record *extents* into contiguous per-partition
-// ranges, LDS-staged so that the writes are runs) and k_core (the resolver; pass A also counts what it forwards
-// by pass B's partitions, so pass B needs no counting kernel).
+// Kernel: k_core (the resolver).  Its input arrives as workgroup-private partitioned runs (sgc_runs.h): the misses of
+// k_count_slices and the generic blocks for pass A, what pass A forwards for pass B — no counting or scatter kernels.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -37,112 +36,12 @@
 #include "sgc_device.h"
 #include "sgc_format.h"
 #include "sgc_kernels.h"
+#include "sgc_runs.h"
 
-#define CP_THREADS 1024u
-#define CP_W 512u                // workgroups of the partition kernels (two per CU)
-#define CP_TILE 4096u
-#define CP_SEG 1024u             // extents scanned per segment
-#define CP_MAXP (1u << SGC_CORE_MAX_LOG2_P)
-#define CP_DROP 0xFFFFu
-#define CP_CUR_STRIDE 8u          // partition cursors 32 bytes apart
+#define CP_MAXP RUN_MAXP
 #define KC_THREADS 1024u
 #define KC_CHUNK 4096u           // records per unit of resolver work
 #define KC_GRID 512u
-
-// Partition of a record, or CP_DROP for a record whose three windows are all dead (a read too short for the
-// Centered window, src/counter.rs:158-166): it cannot match, and all such records are identical, so they
-// would pile up in one partition.
-__device__ __forceinline__ uint32_t cp_part(uint64_t rec, uint32_t cs2, uint64_t cmask, uint32_t log2_p, uint32_t sh,
-                                            uint32_t dead_all) {
-    if ((uint32_t)(rec >> sh) == dead_all) return CP_DROP;
-    return sgc_core_part(sgc_core_hash((uint32_t)((rec >> cs2) & cmask)), log2_p);
-}
-
-// map[j] = 1 + the extent (index inside the segment) that holds flat position r0 + j, for the CP_TILE
-// positions of a tile.  Thread t owns extent t (offset my_off, my_cnt records): it plants its number where
-// its extent starts (or at position 0 if the extent straddles r0); a running maximum over the positions —
-// four per thread, then waves, then the workgroup — spreads every number up to the next start.  Far fewer
-// instructions than a binary search per record.
-__device__ __forceinline__ void build_tile_map(uint16_t *map, uint32_t my_off, uint32_t my_cnt, uint32_t r0, uint32_t *wmax) {
-    static_assert(CP_TILE == 4 * CP_THREADS, "four map entries per thread");
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    uint64_t *m64 = reinterpret_cast<uint64_t *>(map);
-    m64[t] = 0;
-    __syncthreads();
-    if (my_cnt) {
-        if (my_off >= r0) { if (my_off - r0 < CP_TILE) map[my_off - r0] = (uint16_t)(t + 1); }
-        else if (my_off + my_cnt > r0) map[0] = (uint16_t)(t + 1);
-    }
-    __syncthreads();
-    const uint64_t v = m64[t];
-    uint32_t h0 = (uint32_t)(v & 0xFFFF), h1 = (uint32_t)((v >> 16) & 0xFFFF), h2 = (uint32_t)((v >> 32) & 0xFFFF), h3 = (uint32_t)(v >> 48);
-    h1 = h1 > h0 ? h1 : h0; h2 = h2 > h1 ? h2 : h1; h3 = h3 > h2 ? h3 : h2;
-    uint32_t incl = h3;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t x = __shfl_up(incl, off, 64);
-        if ((int)lane >= off && x > incl) incl = x;
-    }
-    if (lane == 63) wmax[wave] = incl;
-    uint32_t before = __shfl_up(incl, 1, 64);
-    if (lane == 0) before = 0;
-    __syncthreads();
-    for (uint32_t w = 0; w < wave; w++) { const uint32_t x = wmax[w]; before = x > before ? x : before; }
-    h0 = h0 > before ? h0 : before; h1 = h1 > before ? h1 : before; h2 = h2 > before ? h2 : before; h3 = h3 > before ? h3 : before;
-    m64[t] = (uint64_t)h0 | ((uint64_t)h1 << 16) | ((uint64_t)h2 << 32) | ((uint64_t)h3 << 48);
-    __syncthreads();
-}
-
-// ------------------------------------------------------------------------------------------------ partition
-// Input: E extents of records; extent e holds (ext_cnt[e] & cnt_mask) records starting at record index
-// ext_off[e] (or e * stride when ext_off is NULL — the blocks of the slice-partitioned pool).  Workgroup w
-// owns extents [w * per, (w + 1) * per); a segment of extents is walked as one flat range of records.
-struct cp_args {
-    const uint64_t *in;
-    const uint32_t *ext_off, *ext_cnt;
-    uint32_t cnt_mask, stride, E, per, cs2, log2_p, sh, dead_all, dbg;
-    uint64_t cmask;
-};
-
-// records per partition, added to tot[] (zeroed by the caller)
-__global__ void __launch_bounds__(CP_THREADS) k_cp_count(cp_args a, uint32_t *__restrict__ tot) {
-    __shared__ uint32_t h[CP_MAXP], off_[CP_SEG], wsum[17];
-    __shared__ __attribute__((aligned(8))) uint16_t map[CP_TILE];
-    const uint32_t t = threadIdx.x, P = 1u << a.log2_p;
-    const uint32_t e0 = blockIdx.x * a.per, e1 = e0 + a.per < a.E ? e0 + a.per : a.E;
-    if (t < CP_MAXP) h[t] = 0;
-    for (uint32_t s0 = e0; s0 < e1; s0 += CP_SEG) {
-        const uint32_t ns = e1 - s0 < CP_SEG ? e1 - s0 : CP_SEG;
-        const uint32_t c = t < ns ? (a.ext_cnt[s0 + t] & a.cnt_mask) : 0;
-        uint32_t T;
-        const uint32_t my_off = wg_scan_1024(c, wsum, &T);
-        off_[t] = my_off;
-        __syncthreads();
-        for (uint32_t r0 = 0; r0 < T; r0 += CP_TILE) {
-            build_tile_map(map, my_off, c, r0, wsum);
-            uint64_t rec[CP_TILE / CP_THREADS];
-#pragma unroll
-            for (uint32_t k = 0; k < CP_TILE / CP_THREADS; k++) {       // all loads first: they overlap
-                const uint32_t d = r0 + k * CP_THREADS + t;
-                if (d < T) {
-                    const uint32_t u = map[d - r0] - 1u;
-                    rec[k] = a.in[(a.ext_off ? (uint64_t)a.ext_off[s0 + u] : (uint64_t)(s0 + u) * a.stride) + (d - off_[u])];
-                }
-            }
-#pragma unroll
-            for (uint32_t k = 0; k < CP_TILE / CP_THREADS; k++) {
-                const uint32_t d = r0 + k * CP_THREADS + t;
-                if (d < T) {
-                    const uint32_t p = cp_part(rec[k], a.cs2, a.cmask, a.log2_p, a.sh, a.dead_all);
-                    if (p != CP_DROP) atomicAdd(&h[p], 1u);
-                }
-            }
-        }
-        __syncthreads();
-    }
-    __syncthreads();
-    if (t < P && h[t]) atomicAdd(&tot[t], h[t]);
-}
 
 // tot[] (records per partition) -> ps[p] = first record of partition p (ps[P] = total) and cs[p] = first
 // KC_CHUNK-record chunk of partition p (cs[P] = number of chunks); ps/cs: LDS arrays of P + 1 entries
@@ -158,97 +57,31 @@ __device__ __forceinline__ void starts_from_totals(const uint32_t *__restrict__ 
     __syncthreads();
 }
 
-// Partition p's output range starts at ps[p] (from tot[]); a tile's run for p goes where an atomic on cursor[p]
-// (zeroed by the caller) says: the order of the runs inside a partition is whatever the race gives, which no
-// consumer depends on.
-__global__ void __launch_bounds__(CP_THREADS) k_cp_scatter(cp_args a, const uint32_t *__restrict__ tot,
-                                                           uint32_t *__restrict__ cursor, uint64_t *__restrict__ out) {
-    __shared__ uint64_t stage[CP_TILE];
-    __shared__ uint16_t stage_p[CP_TILE];
-    __shared__ uint32_t cnt[CP_MAXP], start[CP_MAXP], cur[CP_MAXP], ps[CP_MAXP + 1];
-    __shared__ uint32_t off_[CP_SEG], wsum[17];
-    __shared__ __attribute__((aligned(8))) uint16_t map[CP_TILE];
-    const uint32_t t = threadIdx.x, P = 1u << a.log2_p;
-    const uint32_t e0 = blockIdx.x * a.per, e1 = e0 + a.per < a.E ? e0 + a.per : a.E;
-    if (e0 >= e1) return;
-    starts_from_totals(tot, P, ps, nullptr, wsum);
-    for (uint32_t s0 = e0; s0 < e1; s0 += CP_SEG) {
-        const uint32_t ns = e1 - s0 < CP_SEG ? e1 - s0 : CP_SEG;
-        const uint32_t c = t < ns ? (a.ext_cnt[s0 + t] & a.cnt_mask) : 0;
-        uint32_t T;
-        const uint32_t my_off = wg_scan_1024(c, wsum, &T);
-        off_[t] = my_off;
-        __syncthreads();
-        for (uint32_t r0 = 0; r0 < T; r0 += CP_TILE) {
-            const uint32_t m = T - r0 < CP_TILE ? T - r0 : CP_TILE;
-            if (t < CP_MAXP) cnt[t] = 0;
-            build_tile_map(map, my_off, c, r0, wsum);
-            uint64_t rec[CP_TILE / CP_THREADS];
-            uint32_t pr[CP_TILE / CP_THREADS];
-#pragma unroll
-            for (uint32_t k = 0; k < CP_TILE / CP_THREADS; k++) {
-                const uint32_t j = k * CP_THREADS + t;
-                if (j < m) {
-                    const uint32_t d = r0 + j, u = map[j] - 1u;
-                    rec[k] = a.in[(a.ext_off ? (uint64_t)a.ext_off[s0 + u] : (uint64_t)(s0 + u) * a.stride) + (d - off_[u])];
-                }
-            }
-#pragma unroll
-            for (uint32_t k = 0; k < CP_TILE / CP_THREADS; k++) {
-                const uint32_t j = k * CP_THREADS + t;
-                pr[k] = 0xFFFFFFFFu;
-                if (j < m) {
-                    const uint32_t p = cp_part(rec[k], a.cs2, a.cmask, a.log2_p, a.sh, a.dead_all);
-                    if (p != CP_DROP) pr[k] = (p << 16) | atomicAdd(&cnt[p], 1u);
-                }
-            }
-            __syncthreads();
-            // reserve the tile's runs: the atomics travel to the L2 and back while the scan and the staging go on
-            const uint32_t cc = t < P ? cnt[t] : 0;
-            uint32_t got = 0, kept;
-            if (cc && !(a.dbg & 16384)) got = atomicAdd(&cursor[t * CP_CUR_STRIDE], cc);
-            const uint32_t st0 = wg_scan_1024(cc, wsum, &kept);
-            if (t < P) start[t] = st0;
-            __syncthreads();
-#pragma unroll
-            for (uint32_t k = 0; k < CP_TILE / CP_THREADS; k++) {
-                if (pr[k] != 0xFFFFFFFFu) {
-                    const uint32_t at = start[pr[k] >> 16] + (pr[k] & 0xFFFFu);
-                    stage[at] = rec[k];
-                    stage_p[at] = (uint16_t)(pr[k] >> 16);
-                }
-            }
-            if (t < P) cur[t] = ps[t] + got - st0;          // stage position j of partition p goes to cur[p] + j
-            __syncthreads();
-            for (uint32_t j = t; j < kept && !(a.dbg & 32768); j += CP_THREADS) out[(uint64_t)(cur[stage_p[j]] + j)] = stage[j];
-            __syncthreads();
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ resolver
-// The partitioned records are cut into chunks of KC_CHUNK (never across a partition boundary); workgroup w of
-// KC_GRID takes the w-th equal share of the chunk list — a run of consecutive chunks, so it stages a new
-// partition's table only when its run crosses into the next partition, and a partition swollen by identical
-// reads is shared by as many workgroups as it has chunks.
-// FINAL = false (pass A): records with an undecided higher level are written to fwd[], from the start of the
-// workgroup's run (ext_off/ext_cnt[workgroup] describe what was written).  FINAL = true (pass B): undecided = no.
+// A partition's records (the concatenation of the segments the producers left for it, in.cnt / in.off row p) are cut
+// into chunks of KC_CHUNK; workgroup w of KC_GRID takes the w-th equal share of the chunk list of all partitions — a
+// run of consecutive chunks, so it stages a new partition's table only when its run crosses into the next partition,
+// and a partition swollen by identical reads is shared by as many workgroups as it has chunks.
+// FINAL = false (pass A): records with an undecided higher level are written to fwd[] (one run per workgroup, from the
+// position of its first input record in the partition-ordered numbering — it forwards at most what it reads), counted
+// by pass B's partitions on the way, and laid out as pass B's runs by the epilogue.  FINAL = true (pass B): undecided = no.
 template <bool FINAL>
 __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(80))) k_core(
-    const uint64_t *__restrict__ in, const uint32_t *__restrict__ tot, sgc_core_view cv, const ulonglong2 *__restrict__ amb,
-    uint32_t L, sgc_table_view lib, sgc_table_view perm, uint64_t *__restrict__ fwd, uint32_t *__restrict__ ext_off,
-    uint32_t *__restrict__ ext_cnt, sgc_core_view nx, uint32_t *__restrict__ tot_next, uint32_t *__restrict__ counts,
-    unsigned long long *__restrict__ matched, uint32_t dbg) {
+    const sgc_runs in, sgc_core_view cv, const ulonglong2 *__restrict__ amb, uint32_t L, sgc_table_view lib, sgc_table_view perm,
+    uint64_t *__restrict__ fwd, const sgc_runs out, uint32_t *__restrict__ counts, unsigned long long *__restrict__ matched,
+    uint32_t dbg) {
     __shared__ uint64_t ent[SGC_CORE_EMAX];
     __shared__ uint32_t tgid[SGC_CORE_EMAX], cnt[SGC_CORE_EMAX];
     __shared__ uint16_t start[SGC_CORE_STARTS];
-    __shared__ uint32_t ps[CP_MAXP + 1], cs_[CP_MAXP + 1], hn[FINAL ? 1 : CP_MAXP], wtmp[17];
-    __shared__ uint32_t n_fwd;
+    __shared__ uint32_t ps[CP_MAXP + 1], cs_[CP_MAXP + 1], hn[FINAL ? 1 : CP_MAXP], rcur[FINAL ? 1 : CP_MAXP], wtmp[17];
+    __shared__ uint32_t segpre[KC_THREADS], segoff[KC_THREADS];      // the segments of the current partition: prefix of counts, starts
+    __shared__ uint32_t cmap[2][KC_CHUNK / 64u];
+    __shared__ uint32_t n_fwd, rbase;
     __shared__ unsigned long long wsum;
     const uint32_t t = threadIdx.x, P = 1u << cv.log2_p;
     if (t == 0) { n_fwd = 0; wsum = 0; }
     if (!FINAL && t < CP_MAXP) hn[t] = 0;                  // what this workgroup forwards, by the next pass's partition
-    starts_from_totals(tot, P, ps, cs_, wtmp);
+    starts_from_totals(in.tot, P, ps, cs_, wtmp);
     const uint32_t C = cs_[P];
     const uint32_t c_lo = (uint32_t)((uint64_t)blockIdx.x * C / gridDim.x), c_hi = (uint32_t)((uint64_t)(blockIdx.x + 1) * C / gridDim.x);
     const uint32_t K = L + 2, sh = 2 * K, cs2 = 2 * cv.cs, cl = cv.cl, kdiv = (1u << 20) / K + 1u;
@@ -275,18 +108,40 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             const uint32_t *gs = reinterpret_cast<const uint32_t *>(cv.starts + (size_t)p * SGC_CORE_STARTS);
             for (uint32_t i = t; i < SGC_CORE_EMAX; i += KC_THREADS) { ent[i] = ge[i]; tgid[i] = gg[i]; cnt[i] = 0; }
             for (uint32_t i = t; i < SGC_CORE_STARTS / 2; i += KC_THREADS) reinterpret_cast<uint32_t *>(start)[i] = gs[i];
+            // the partition's segments, one per producer workgroup (in.W <= KC_THREADS)
+            uint32_t seg_total;
+            const uint32_t sc = t < in.W ? in.cnt[(size_t)p * in.W + t] : 0u;
+            const uint32_t sp = wg_scan_1024(sc, wtmp, &seg_total);
+            segpre[t] = sp;
+            segoff[t] = t < in.W ? in.off[(size_t)p * in.W + t] : 0u;
             __syncthreads();
             cur_p = p;
         }
-        const uint32_t lo = ps[p] + (ch - cs_[p]) * KC_CHUNK, hi = lo + KC_CHUNK < ps[p + 1] ? lo + KC_CHUNK : ps[p + 1];
+        // [lo, hi): the chunk in the partition-ordered numbering of all records; x0: its first record inside the partition
+        const uint32_t x0 = (ch - cs_[p]) * KC_CHUNK;
+        const uint32_t lo = ps[p] + x0, hi = lo + KC_CHUNK < ps[p + 1] ? lo + KC_CHUNK : ps[p + 1];
         if (ch == c_lo) wlo = lo;
         // the chunk's records first (KC_CHUNK / KC_THREADS loads in flight), then one at a time
         uint64_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
         static_assert(KC_CHUNK == 4 * KC_THREADS, "the register queue below holds four records");
-        if (lo + t < hi) r0 = __builtin_nontemporal_load(&in[lo + t]);
-        if (lo + KC_THREADS + t < hi) r1 = __builtin_nontemporal_load(&in[lo + KC_THREADS + t]);
-        if (lo + 2 * KC_THREADS + t < hi) r2 = __builtin_nontemporal_load(&in[lo + 2 * KC_THREADS + t]);
-        if (lo + 3 * KC_THREADS + t < hi) r3 = __builtin_nontemporal_load(&in[lo + 3 * KC_THREADS + t]);
+        {
+            // which segment holds record x of the partition: one search per 64 records (lane i of the first wave, for
+            // record x0 + 64 i), then every lane walks on from there — segments are ~100 records long
+            const uint32_t m = hi - lo;
+            uint32_t *cm = cmap[(ch - c_lo) & 1u];
+            if (t < KC_CHUNK / 64u) cm[t] = find_extent<10>(segpre, in.W, x0 + 64u * t < x0 + m ? x0 + 64u * t : x0 + m - 1u);
+            __syncthreads();
+            uint32_t x, w;
+#define KC_LOAD(dst, k)                                                                                         \
+            x = (k) * KC_THREADS + t;                                                                             \
+            if (x < m) {                                                                                          \
+                w = cm[x >> 6];                                                                                   \
+                while (w + 1u < in.W && segpre[w + 1u] <= x0 + x) w++;                                           \
+                dst = __builtin_nontemporal_load(&in.recs[segoff[w] + (x0 + x - segpre[w])]);                    \
+            }
+            KC_LOAD(r0, 0u) KC_LOAD(r1, 1u) KC_LOAD(r2, 2u) KC_LOAD(r3, 3u)
+#undef KC_LOAD
+        }
 #pragma unroll 1
         for (uint32_t i0 = lo; i0 < hi; i0 += KC_THREADS) {
             const bool valid = i0 + t < hi;
@@ -370,7 +225,16 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 lm &= lm - 1u;                   // ambiguous child: this level fails, on to the next
                 lvl = 6; res = SGC_NONE;
             }
-            const uint32_t unk_above = um & ((1u << lvl) - 1u);
+            uint32_t unk_above = um & ((1u << lvl) - 1u);
+            if (!FINAL && unk_above && cv.filt) {
+                // a clean window that saw no candidate here: a clear bit of the rest filter proves that no parent hides
+                // inside the core either ('N' inside the core — unk — stays undecided)
+                const uint32_t cand = unk_above & ~(((unk & 2u) ? 2u : 0u) | ((unk & 4u) ? 8u : 0u) | ((unk & 1u) ? 32u : 0u));
+                const uint32_t fw = 1u << (cv.filt_log2 - 5);
+                if (cand & 2u) { const uint32_t x = sgc_rest_hash(R1, cv.filt_log2); if (!((cv.filt[fw + (x >> 5)] >> (x & 31u)) & 1u)) unk_above &= ~2u; }
+                if (cand & 8u) { const uint32_t x = sgc_rest_hash(R2, cv.filt_log2); if (!((cv.filt[2u * fw + (x >> 5)] >> (x & 31u)) & 1u)) unk_above &= ~8u; }
+                if (cand & 32u) { const uint32_t x = sgc_rest_hash(R0, cv.filt_log2); if (!((cv.filt[x >> 5] >> (x & 31u)) & 1u)) unk_above &= ~32u; }
+            }
             if (dbg & 512) { const unsigned long long x = __builtin_amdgcn_s_memtime(); ts_dec += x - tsa; tsa = x; }
             bool fwd_it = false;
             if (valid) {
@@ -411,7 +275,8 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                     b0 = __shfl(b0, __builtin_ctzll(bal), 64);
                     if (fwd_it && !(dbg & 4096)) {
                         fwd[(uint64_t)wlo + b0 + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = rec;
-                        atomicAdd(&hn[sgc_core_part(sgc_core_hash((uint32_t)((rec >> (2 * nx.cs)) & ((1ull << (2 * nx.cl)) - 1ull))), nx.log2_p)], 1u);
+                        const uint32_t q = run_part(out, rec);
+                        if (q != RUN_DROP) atomicAdd(&hn[q], 1u);
                     }
                 }
             }
@@ -430,67 +295,78 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
     if ((t & 63) == 0 && local) atomicAdd(&wsum, (unsigned long long)local);
     __syncthreads();
-    if (t == 0) {
-        if (wsum) atomicAdd(matched, wsum);
-        if (!FINAL) { ext_off[blockIdx.x] = wlo; ext_cnt[blockIdx.x] = n_fwd; }
+    if (t == 0 && wsum) atomicAdd(matched, wsum);
+    if (!FINAL) {
+        // epilogue (sgc_runs.h): the forwarded run of this workgroup, laid out by pass B's partitions in a region of its own
+        __syncthreads();
+        run_reserve(out, blockIdx.x, hn, rcur, wtmp, &rbase);
+        const uint32_t nf = n_fwd;
+        for (uint32_t j0 = 0; j0 < nf && !(dbg & (4096u | 524288u)); j0 += 4 * KC_THREADS) {
+            uint64_t r[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) { const uint32_t j = j0 + k * KC_THREADS + t; if (j < nf) r[k] = fwd[(uint64_t)wlo + j]; }
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t j = j0 + k * KC_THREADS + t;
+                if (j < nf) run_place(out, rcur, r[k]);
+            }
+        }
     }
-    if (!FINAL && t < (1u << nx.log2_p) && hn[t]) atomicAdd(&tot_next[t], hn[t]);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-void sgc_core_plan(uint64_t n, const sgc_core_view &a, const sgc_core_view &b, sgc_core_geometry *g) {
-    (void)a; (void)b;
-    g->w = CP_W;
+// Scratch of the two passes: recs_bytes for each of two record buffers (pass A's runs; pass A's forwarded runs — pass B's
+// runs go to the slice pool, which is dead once k_count_slices has handed its leftovers on), small_bytes for the four
+// [P][W] matrices, zero_bytes of zeroed words (totals A | totals B | region cursors), which live in the zeroed tail of
+// the descriptor buffer.
+void sgc_core_plan(uint64_t n, const sgc_core_view &a, const sgc_core_view &b, uint32_t producers_a, sgc_core_geometry *g) {
+    g->w = producers_a;
     g->grid_a = g->grid_b = KC_GRID;
-    g->recs_bytes = n * 8;                                        // each of the two record buffers
-    g->zero_bytes = (size_t)(2 + 2 * CP_CUR_STRIDE) * CP_MAXP * 4;   // totals A | totals B | cursors A | cursors B
-    g->small_bytes = (size_t)2 * KC_GRID * 4;                     // the extents pass A hands to pass B
+    g->recs_bytes = n * 8;
+    g->zero_bytes = (size_t)(2 * CP_MAXP + 2) * 4;
+    static_assert((2 * CP_MAXP + 2) * 4 <= SGC_DESC_TAIL, "the zeroed tail of the descriptor buffer holds the counters");
+    g->mat_a = ((size_t)producers_a << a.log2_p) * 4;          // bytes of ONE matrix of pass A's runs
+    g->mat_b = ((size_t)KC_GRID << b.log2_p) * 4;
+    g->small_bytes = 2 * g->mat_a + 2 * g->mat_b;
 }
 
-static cp_args partition_args(const uint64_t *in, const uint32_t *ext_off, const uint32_t *ext_cnt, uint32_t cnt_mask,
-                              uint32_t stride, uint32_t E, const sgc_core_view &cv, uint32_t L, uint32_t dbg) {
+static sgc_runs make_runs(uint64_t *recs, void *mats, size_t mat_bytes, uint32_t *tot, uint32_t *cursor, uint32_t W,
+                          const sgc_core_view &cv, uint32_t L) {
     const uint32_t K = L + 2;
-    cp_args a;
-    a.in = in; a.ext_off = ext_off; a.ext_cnt = ext_cnt; a.cnt_mask = cnt_mask; a.stride = stride; a.E = E;
-    a.per = (E + CP_W - 1) / CP_W; a.cs2 = 2 * cv.cs; a.log2_p = cv.log2_p; a.sh = 2 * K;
-    a.dead_all = SGC_STATE_DEAD * (1 + K + K * K);
-    a.cmask = (1ull << (2 * cv.cl)) - 1ull;
-    a.dbg = dbg;
-    return a;
+    sgc_runs r;
+    r.recs = recs; r.cnt = (uint32_t *)mats; r.off = (uint32_t *)((char *)mats + mat_bytes); r.tot = tot; r.cursor = cursor; r.W = W;
+    r.cs2 = 2 * cv.cs; r.log2_p = cv.log2_p; r.sh = 2 * K; r.dead_all = SGC_STATE_DEAD * (1 + K + K * K);
+    r.cmask = (1ull << (2 * cv.cl)) - 1ull;
+    return r;
 }
 
-void sgc_launch_core(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm,
+// what k_count_slices' epilogue fills: the runs of pass A
+sgc_runs sgc_core_runs_a(const sgc_core_geometry &g, const sgc_core_view &ca, uint32_t L, uint64_t *buf0, void *zeroed, void *small) {
+    uint32_t *z = (uint32_t *)zeroed;
+    return make_runs(buf0, small, g.mat_a, z, z + 2 * CP_MAXP, g.w, ca, L);
+}
+
+void sgc_launch_core(hipStream_t st, int pass, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm,
                      const sgc_core_view &ca, const sgc_core_view &cb, const uint64_t *amb, const sgc_core_geometry &g,
-                     const uint64_t *pool, const uint32_t *desc, uint32_t n_blocks, uint32_t block_records,
-                     uint64_t *buf0, uint64_t *buf1, void *zeroed, void *small, uint32_t *counts, unsigned long long *matched,
-                     uint32_t dbg) {
-    (void)g;
-    uint32_t *tot_a = (uint32_t *)zeroed, *tot_b = tot_a + CP_MAXP, *cur_a = tot_b + CP_MAXP, *cur_b = cur_a + CP_MAXP * CP_CUR_STRIDE;
-    static_assert((2 + 2 * CP_CUR_STRIDE) * CP_MAXP * 4 <= SGC_DESC_TAIL, "the zeroed tail of the descriptor buffer holds the counters");
-    uint32_t *ext_off = (uint32_t *)small, *ext_cnt = ext_off + KC_GRID;
+                     uint64_t *buf0, uint64_t *buf1, uint64_t *buf2, void *zeroed, void *small, uint32_t *counts,
+                     unsigned long long *matched, uint32_t dbg) {
+    uint32_t *z = (uint32_t *)zeroed;
     const ulonglong2 *am = reinterpret_cast<const ulonglong2 *>(amb);
-    // pass A: the blocks of the slice-partitioned pool (K2 left the misses at the block fronts) -> buf0
-    const cp_args pa = partition_args(pool, nullptr, desc, 0xFFFFu, block_records, n_blocks, ca, L, dbg);
-    hipLaunchKernelGGL(k_cp_count, dim3(CP_W), dim3(CP_THREADS), 0, st, pa, tot_a);
-    hipLaunchKernelGGL(k_cp_scatter, dim3(CP_W), dim3(CP_THREADS), 0, st, pa, tot_a, cur_a, buf0);
-    hipLaunchKernelGGL((k_core<false>), dim3(KC_GRID), dim3(KC_THREADS), 0, st, buf0, tot_a, ca, am, L, lib, perm, buf1, ext_off,
-                       ext_cnt, cb, tot_b, counts, matched, dbg);
-    // pass B: what pass A forwarded (one run per pass-A workgroup in buf1; it also counted them by partition) -> buf0
-    const cp_args pb = partition_args(buf1, ext_off, ext_cnt, 0xFFFFFFFFu, 0, KC_GRID, cb, L, dbg);
-    hipLaunchKernelGGL(k_cp_scatter, dim3(CP_W), dim3(CP_THREADS), 0, st, pb, tot_b, cur_b, buf0);
-    hipLaunchKernelGGL((k_core<true>), dim3(KC_GRID), dim3(KC_THREADS), 0, st, buf0, tot_b, cb, am, L, lib, perm,
-                       (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, cb, (uint32_t *)nullptr, counts, matched, dbg);
+    const sgc_runs ra = sgc_core_runs_a(g, ca, L, buf0, zeroed, small);
+    const sgc_runs rb = make_runs(buf2, (char *)small + 2 * g.mat_a, g.mat_b, z + CP_MAXP, z + 2 * CP_MAXP + 1, KC_GRID, cb, L);
+    if (pass == 0)      // pass A: the runs k_count_slices left in buf0; forwards go to buf1 run by run, then to buf2 as pass B's runs
+        hipLaunchKernelGGL((k_core<false>), dim3(KC_GRID), dim3(KC_THREADS), 0, st, ra, ca, am, L, lib, perm, buf1, rb, counts, matched, dbg);
+    else                // pass B: what pass A forwarded
+        hipLaunchKernelGGL((k_core<true>), dim3(KC_GRID), dim3(KC_THREADS), 0, st, rb, cb, am, L, lib, perm, (uint64_t *)nullptr, rb,
+                           counts, matched, dbg);
 }
 
 // diagnostic (sgc_set_option "print_occupancy"): resident workgroups per CU as the runtime computes them
 void sgc_core_print_occupancy() {
-    int a = -1, b = -1, c = -1, d = -1;
+    int a = -1, b = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_core<false>, KC_THREADS, 0);
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_core<true>, KC_THREADS, 0);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, k_cp_scatter, CP_THREADS, 0);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&d, k_cp_count, CP_THREADS, 0);
     hipFuncAttributes fa;
     (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_core<false>));
-    fprintf(stderr, "occupancy (workgroups/CU): k_core<A> %d k_core<B> %d k_cp_scatter %d k_cp_count %d; k_core<A> lds %zu regs %d\n", a, b, c, d,
-            fa.sharedSizeBytes, fa.numRegs);
+    fprintf(stderr, "occupancy (workgroups/CU): k_core<A> %d k_core<B> %d; k_core<A> lds %zu regs %d\n", a, b, fa.sharedSizeBytes, fa.numRegs);
 }

@@ -111,8 +111,15 @@ struct sgc_core_view {
     const uint64_t *ents;
     const uint32_t *gids;
     const uint16_t *starts;
-    uint32_t log2_p, cs, cl, pad_;
+    uint32_t log2_p, cs, cl, filt_log2;
+    // Rest filter (optional, core A only): three bit sets of 2^filt_log2 bits, one per alignment; bit
+    // sgc_rest_hash(rest) of set a is on iff some guide has that rest at alignment a.  A clean window that found no
+    // candidate through this core can only have a single-mismatch parent whose substitution lies INSIDE the core, and
+    // such a parent agrees with the window on the whole rest: a clear bit proves there is none, so the pass can settle
+    // the level instead of forwarding the record to the other core's pass (false positives only cost a forward).
+    const uint32_t *filt;
 };
+SGC_HD uint32_t sgc_rest_hash(uint32_t rest, uint32_t log2_bits) { return (rest * 0x9E3779B1u) >> (32 - log2_bits); }
 // 32-bit hash of a core value (<= 28 bits): its top bits pick the partition, the next ones the bucket
 SGC_HD uint32_t sgc_core_hash(uint32_t corev) {
     uint32_t h = corev * 0x9E3779B1u;

@@ -47,8 +47,12 @@ bool sgc_part_supported(const sgc_table_view &lib, bool rec16);
 void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_part_geometry *g);
 void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib,
                         const sgc_part_geometry &g, uint64_t *pool, uint32_t *desc);
+struct sgc_runs;       // sgc_runs.h
+// runs != NULL: the leftovers (misses, generic blocks) are laid out as the runs of core pass A by the kernel's epilogue
+uint32_t sgc_part_k2_grid(const sgc_part_geometry &g);
 void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_part_geometry &g,
-                        uint64_t *pool, uint32_t *desc, uint32_t *counts, unsigned long long *matched, uint32_t dbg);
+                        uint64_t *pool, uint32_t *desc, uint32_t *counts, unsigned long long *matched, uint32_t dbg,
+                        const sgc_runs *runs);
 void sgc_launch_part_k3(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm,
                         const sgc_bloom_view &bloom_lib, const sgc_bloom_view &bloom_perm, const sgc_part_geometry &g,
                         const uint64_t *pool, const uint32_t *desc, uint32_t *seg_cnt, uint32_t *gids, uint32_t dbg);
@@ -60,16 +64,17 @@ void sgc_launch_part_k4(hipStream_t st, uint32_t n_guides, const sgc_part_geomet
 
 // ---- single-mismatch resolution in LDS (sgc_core.hip) -------------------------------------------
 struct sgc_core_geometry {
-    uint32_t w, grid_a, grid_b, pad_;
-    uint64_t recs_bytes, zero_bytes, small_bytes;
+    uint32_t w, grid_a, grid_b, pad_;       // w: producer workgroups of pass A's runs (the grid of k_count_slices)
+    uint64_t recs_bytes, zero_bytes, small_bytes, mat_a, mat_b;
 };
-void sgc_core_plan(uint64_t n, const sgc_core_view &a, const sgc_core_view &b, sgc_core_geometry *g);
-// pool/desc: the slice-partitioned blocks after k_count_slices; buf0/buf1: recs_bytes each; zeroed: zero_bytes of
-// zeros (stream-ordered before the call); small: small_bytes
-void sgc_launch_core(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm,
+void sgc_core_plan(uint64_t n, const sgc_core_view &a, const sgc_core_view &b, uint32_t producers_a, sgc_core_geometry *g);
+// buf0/buf1: recs_bytes each (pass A's runs, pass A's forwarded runs); buf2: recs_bytes, pass B's runs (the slice pool may
+// serve: it is dead by then); zeroed: zero_bytes of zeros (stream-ordered before k_count_slices); small: small_bytes
+sgc_runs sgc_core_runs_a(const sgc_core_geometry &g, const sgc_core_view &ca, uint32_t L, uint64_t *buf0, void *zeroed, void *small);
+// pass: 0 = core A (reads buf0, forwards through buf1 into buf2), 1 = core B (reads buf2)
+void sgc_launch_core(hipStream_t st, int pass, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm,
                      const sgc_core_view &ca, const sgc_core_view &cb, const uint64_t *amb, const sgc_core_geometry &g,
-                     const uint64_t *pool, const uint32_t *desc, uint32_t n_blocks, uint32_t block_records,
-                     uint64_t *buf0, uint64_t *buf1, void *zeroed, void *small, uint32_t *counts,
+                     uint64_t *buf0, uint64_t *buf1, uint64_t *buf2, void *zeroed, void *small, uint32_t *counts,
                      unsigned long long *matched, uint32_t dbg);
 
 void sgc_core_print_occupancy();

@@ -27,6 +27,7 @@
 #include "sgc_device.h"
 #include "sgc_format.h"
 #include "sgc_kernels.h"
+#include "sgc_runs.h"
 
 #ifndef K1_THREADS
 #define K1_THREADS 1024u        // one 16-wave workgroup per CU: few workgroups leave few half-empty blocks open
@@ -43,10 +44,22 @@ static_assert(PART_TILE % PART_BLOCK == 0 || PART_BLOCK % PART_TILE == 0, "tile/
 // (an 'N', a dead window, a short read; ~2 % of reads) — the extra "generic" partition P_lib.  Those records
 // need the serial generic chain (sgc_assign); kept apart, they are resolved by full waves in k_generic
 // instead of stalling one or two lanes of almost every wave of the fast kernels.
-__device__ __forceinline__ uint32_t part_of(uint64_t rec, uint64_t kmask, uint32_t sh, uint32_t log2_slots,
+// A clean record (status 0) has nothing above its span bits, so the partition kernel leaves the key's bucket
+// inside its slice there (PART_TAG_SHIFT: 11 bits, 2 (L + 2) <= 50 for one-word records): k_count_slices then
+// probes without hashing the key a second time — the 64-bit multiply is a dozen quarter-rate vector instructions,
+// and that kernel is bound by vector issue.  Whoever hands a record on (the miss compaction) clears the tag.
+// The misses of a slice block are compacted in place, but not to the block's first slots: every block is 8 KiB-aligned,
+// so fronts that all start at offset 0 would land on the same few L2 / HBM channels (the first KiB of every 8 KiB) for
+// the writer and for every reader.  The front of block b starts at record part_front(b) and wraps inside the block.
+__device__ __forceinline__ uint32_t part_front(uint32_t b) { return ((b * 2654435761u) >> 26) << 4; }      // 64 starts, 128-B aligned
+#define PART_TAG_SHIFT 53u
+#define PART_TAG_MASK ((1ull << PART_TAG_SHIFT) - 1ull)
+__device__ __forceinline__ uint32_t part_of(uint64_t &rec, uint64_t kmask, uint32_t sh, uint32_t log2_slots,
                                             uint32_t log2_slice) {
     if ((rec >> sh) != 0) return 1u << (log2_slots - log2_slice);
-    return sgc_slice_of((rec >> 2) & kmask, log2_slots, log2_slice);
+    const uint32_t hb = sgc_home_bucket((rec >> 2) & kmask, log2_slots);
+    rec |= (uint64_t)(hb & ((1u << (log2_slice - 1)) - 1u)) << PART_TAG_SHIFT;
+    return hb >> (log2_slice - 1);
 }
 
 // ------------------------------------------------------------------------------------------------ K1
@@ -70,6 +83,14 @@ __global__ void __launch_bounds__(K1_THREADS) k_partition(const uint64_t *__rest
     if (t < PART_ARR) { blk[t] = 0xFFFFFFFFu; fill[t] = PART_BLOCK; nblk[t] = 0; }
     if (t == 0) next_free = 0;
     __syncthreads();
+    // the records of the NEXT tile are requested before the current one is processed: one workgroup per CU walks
+    // its tiles in lockstep phases, so without this the HBM latency of every tile's loads is fully exposed
+    uint64_t nxt[PART_TILE / K1_THREADS];
+#pragma unroll
+    for (uint32_t k = 0; k < PART_TILE / K1_THREADS; k++) {
+        const uint64_t j = lo + (uint64_t)k * K1_THREADS + t;
+        nxt[k] = j < hi ? __builtin_nontemporal_load(&recs[j]) : 0ull;
+    }
     for (uint64_t base = lo; base < hi; base += PART_TILE) {
         const uint32_t m = (uint32_t)(hi - base < PART_TILE ? hi - base : PART_TILE);
         if (t < PART_ARR) cnt[t] = 0;
@@ -77,9 +98,11 @@ __global__ void __launch_bounds__(K1_THREADS) k_partition(const uint64_t *__rest
         uint64_t rec[PART_TILE / K1_THREADS];
         uint32_t pr[PART_TILE / K1_THREADS];     // partition << 16 | rank inside the tile
 #pragma unroll
+        for (uint32_t k = 0; k < PART_TILE / K1_THREADS; k++) rec[k] = nxt[k];
+#pragma unroll
         for (uint32_t k = 0; k < PART_TILE / K1_THREADS; k++) {
-            const uint32_t j = k * K1_THREADS + t;
-            if (j < m) rec[k] = __builtin_nontemporal_load(&recs[base + j]);
+            const uint64_t j = base + PART_TILE + (uint64_t)k * K1_THREADS + t;
+            nxt[k] = j < hi ? __builtin_nontemporal_load(&recs[j]) : 0ull;
         }
 #pragma unroll
         for (uint32_t k = 0; k < PART_TILE / K1_THREADS; k++) {
@@ -180,12 +203,14 @@ __global__ void __launch_bounds__(K1_THREADS) k_partition(const uint64_t *__rest
 #endif
 //                 // blocks per group: one group is processed while the next is in flight
 #define K2_SCAN 16u              // descriptors examined per lane per scan chunk
+#define K2_GLIST 64u             // generic blocks listed per epilogue window
 template <int LOG2_SLICE>
 __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(80))) k_count_slices(uint64_t *__restrict__ pool, uint32_t *__restrict__ desc,
                                                              const uint32_t *__restrict__ wcnt, const uint32_t *__restrict__ wlist,
                                                              uint32_t k1_wgs, uint32_t blocks_per_wg, uint32_t G, uint32_t L,
                                                              sgc_table_view lib, uint32_t *__restrict__ counts,
-                                                             unsigned long long *__restrict__ matched, uint32_t dbg) {
+                                                             unsigned long long *__restrict__ matched, uint32_t dbg,
+                                                             const sgc_runs ep) {
     constexpr uint32_t S = 1u << LOG2_SLICE;
     constexpr uint32_t RPT = PART_BLOCK / K2_THREADS;       // records per thread per block
     constexpr uint32_t Q = K2_U * RPT;                       // records per thread per group
@@ -193,6 +218,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     __shared__ uint32_t cnt[S];
     __shared__ uint32_t list[K2_LIST];                       // block id << 11 | (fill - 1)
     __shared__ uint32_t miss_cnt[2][K2_U], scratch[128], pre[K2_THREADS], wtmp[17];
+    __shared__ uint32_t hn[RUN_MAXP], rcur[RUN_MAXP], rbase, preg[K2_THREADS];   // epilogue: leftovers by partition of core pass A
     const uint32_t t = threadIdx.x, p = blockIdx.x / G, g = blockIdx.x % G;
     const uint32_t slice = lib.log2_slice < (uint32_t)LOG2_SLICE ? (1u << lib.log2_slice) : S;   // small libraries
     const uint32_t bmask = slice / 2 - 1u, gid_bits = lib.gid_bits;
@@ -205,6 +231,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
         tab[i] = v;
     }
     for (uint32_t i = t; i < S; i += K2_THREADS) cnt[i] = 0;
+    for (uint32_t i = t; i < RUN_MAXP; i += K2_THREADS) hn[i] = 0;
     if (t < 2 * K2_U) miss_cnt[t / K2_U][t % K2_U] = 0;
     // diagnostic stamps (dbg & 512): cycle counts of the phases of a few workgroups, printed at the end
     unsigned long long ts0 = 0, ts_scan = 0, ts_loop = 0;
@@ -272,7 +299,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 const uint32_t u = q / RPT, j = (q % RPT) * K2_THREADS + t;
                 const bool valid = ce[u] != 0xFFFFFFFFu && j <= (ce[u] & 2047u);
                 const uint64_t key = (cur[q] >> 2) & kmask;
-                uint32_t b = sgc_home_bucket(key, lib.log2_slots) & bmask;
+                uint32_t b = (uint32_t)(cur[q] >> PART_TAG_SHIFT);           // left there by k_partition
                 ulonglong2 wv = tab[b];
                 bool hit = wv.x == key || wv.y == key;
                 bool cont = valid && !hit && wv.y != SGC_EMPTY;
@@ -287,7 +314,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 const bool hv = valid && hit, mv = valid && !hit;
                 atomicAdd(hv ? &cnt[2 * b + (wv.x == key ? 0u : 1u)] : &scratch[t & 63u], 1u);
                 const uint32_t pos = atomicAdd(mv ? &miss_cnt[par][u] : &scratch[64u + (t & 63u)], 1u);
-                if (mv) pool[(uint64_t)(ce[u] >> 11) * PART_BLOCK + pos] = cur[q];
+                if (mv) pool[(uint64_t)(ce[u] >> 11) * PART_BLOCK + ((part_front(ce[u] >> 11) + pos) & (PART_BLOCK - 1u))] = cur[q] & PART_TAG_MASK;
             }
 #pragma unroll
             for (uint32_t q = 0; q < Q; q++) cur[q] = nxt[q];
@@ -327,6 +354,85 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     if ((t & 63) == 0 && local) atomicAdd(&wsum, (unsigned long long)local);
     __syncthreads();
     if (t == 0 && wsum) atomicAdd(matched, wsum);
+    if (!ep.recs || (dbg & 262144u)) return;
+    // Epilogue (sgc_runs.h): what this workgroup could not settle — the misses it compacted to the fronts of its blocks —
+    // and its share of the generic partition's blocks (records with an 'N' or a dead window: nothing to probe here) go to
+    // core pass A, laid out by that pass's partitions in a region of ep.recs of the workgroup's own.  Two sweeps over the
+    // same records (L2-warm: just written): histogram, then placement.  The fronts of a window of blocks are walked as ONE
+    // flat range (prefix of the fills in LDS, a branch-free search per record), four loads in flight per lane.
+    const uint32_t Pg = 1u << (lib.log2_slots - lib.log2_slice);                       // index of the generic partition
+    uint32_t Bg;
+    preg[t] = wg_scan_1024(t < k1_wgs ? wcnt[t * PART_ARR + Pg] : 0u, wtmp, &Bg);
+    const uint32_t g_lo = (uint32_t)((uint64_t)Bg * blockIdx.x / gridDim.x), g_hi = (uint32_t)((uint64_t)Bg * (blockIdx.x + 1) / gridDim.x);
+    __syncthreads();
+    // Every dependent round trip to memory costs ~2.5 us here (the fronts left the L2 long ago), so the sweeps keep many
+    // loads in flight: a wave takes eight block fronts at a time (a front is ~140 records: three 64-lane steps), the
+    // generic blocks (full) are read one record per lane, four blocks at a time; the block lists are built once when
+    // the workgroup's share fits one window (it does, short of extreme skew).
+    __shared__ uint32_t glist[K2_GLIST];
+    const bool one_window = s_hi - s_lo <= K2_LIST && g_hi - g_lo <= K2_GLIST;
+    const uint32_t lane = t & 63u, wave = t >> 6;
+    for (uint32_t sweep = 0; sweep < 2; sweep++) {
+        for (uint32_t ws = s_lo, wg = g_lo; ws < s_hi || wg < g_hi; ws += K2_LIST, wg += K2_GLIST) {
+            const uint32_t nl = ws < s_hi ? (s_hi - ws < K2_LIST ? s_hi - ws : K2_LIST) : 0u;
+            const uint32_t ng = wg < g_hi ? (g_hi - wg < K2_GLIST ? g_hi - wg : K2_GLIST) : 0u;
+            if (!(one_window && sweep == 1)) {
+                __syncthreads();
+                for (uint32_t i = t; i < nl + ng; i += K2_THREADS) {
+                    const bool gen = i >= nl;
+                    const uint32_t *prefix = gen ? preg : pre;
+                    const uint32_t o = gen ? wg + (i - nl) : ws + i, w = find_extent<10>(prefix, k1_wgs, o);
+                    const uint32_t b = wlist[((size_t)w * PART_ARR + (gen ? Pg : p)) * blocks_per_wg + (o - prefix[w])];
+                    const uint32_t e = (b << 11) | (desc[b] & DESC_FILL_MASK);       // fill <= PART_BLOCK = 1024 < 2^11
+                    if (gen) glist[i - nl] = e; else list[i] = e;
+                }
+                __syncthreads();
+            }
+            if (dbg & (65536u << sweep)) continue;
+            // slice blocks: the compacted misses at the (staggered) fronts
+            for (uint32_t i0 = wave; i0 < nl; i0 += 8u * (K2_THREADS / 64u)) {
+                uint32_t e[8], mx = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) {
+                    const uint32_t i = i0 + k * (K2_THREADS / 64u);
+                    e[k] = i < nl ? list[i] : 0u;
+                    const uint32_t f = e[k] & 2047u;
+                    mx = f > mx ? f : mx;
+                }
+                for (uint32_t j = lane; j < mx; j += 64) {
+                    uint64_t r[8];
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++)
+                        if (j < (e[k] & 2047u)) r[k] = pool[(uint64_t)(e[k] >> 11) * PART_BLOCK + ((part_front(e[k] >> 11) + j) & (PART_BLOCK - 1u))];
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) {
+                        if (j >= (e[k] & 2047u)) continue;
+                        if (sweep == 0) { const uint32_t q = run_part(ep, r[k]); if (q != RUN_DROP) atomicAdd(&hn[q], 1u); }
+                        else run_place(ep, rcur, r[k]);
+                    }
+                }
+            }
+            // generic blocks: filled from their first slot, usually full
+            for (uint32_t i0 = 0; i0 < ng; i0 += 4) {
+                uint64_t r[4];
+                uint32_t f[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t e = i0 + k < ng ? glist[i0 + k] : 0u;
+                    f[k] = e & 2047u;
+                    if (t < f[k]) r[k] = pool[(uint64_t)(e >> 11) * PART_BLOCK + t];
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    if (t >= f[k]) continue;
+                    if (sweep == 0) { const uint32_t q = run_part(ep, r[k]); if (q != RUN_DROP) atomicAdd(&hn[q], 1u); }
+                    else run_place(ep, rcur, r[k]);
+                }
+            }
+        }
+        __syncthreads();
+        if (sweep == 0) run_reserve(ep, blockIdx.x, hn, rcur, wtmp, &rbase);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ K3
@@ -390,10 +496,11 @@ __global__ void __launch_bounds__(K3_THREADS) k_resolve_miss(const uint64_t *__r
         for (uint32_t u = t >> 6; u < K3_SEG; u += K3_THREADS / 64) {
             const uint32_t lane = t & 63u;
             const uint64_t *blkp = pool + (uint64_t)(b0 + u) * PART_BLOCK;
+            const uint32_t fr = part_front(b0 + u);
             for (uint32_t j = lane; j < m_[u]; j += 64) {
                 const uint32_t d = off_[u] + j;
                 if (d >= r0 && d < r0 + K3_STAGE) {
-                    const uint64_t rec = __builtin_nontemporal_load(&blkp[j]);
+                    const uint64_t rec = __builtin_nontemporal_load(&blkp[(fr + j) & (PART_BLOCK - 1u)]);
                     if ((rec >> sh) == 0 && !(dbg & 128)) st[atomicAdd(&n_fast, 1u)] = rec;
                     else st[K3_STAGE - 1u - atomicAdd(&n_slow, 1u)] = rec;
                 }
@@ -589,12 +696,18 @@ void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32
                        (uint32_t *)((char *)desc + g.wcnt_off), (uint32_t *)((char *)desc + g.wlist_off));
 }
 
+// workgroups of k_count_slices: G per slice, two per CU in all — one resident generation
+static uint32_t k2_shares(const sgc_part_geometry &g) { return g.partitions >= 512 ? 1 : 512 / g.partitions; }
+uint32_t sgc_part_k2_grid(const sgc_part_geometry &g) { return g.partitions * k2_shares(g); }
+
 void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_part_geometry &g,
-                        uint64_t *pool, uint32_t *desc, uint32_t *counts, unsigned long long *matched, uint32_t dbg) {
-    const uint32_t G = g.partitions >= 512 ? 1 : 512 / g.partitions;     // two workgroups per CU
+                        uint64_t *pool, uint32_t *desc, uint32_t *counts, unsigned long long *matched, uint32_t dbg,
+                        const sgc_runs *runs) {
+    const uint32_t G = k2_shares(g);
+    sgc_runs none{};
     hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE>), dim3(g.partitions * G), dim3(K2_THREADS), 0, st, pool, desc,
                        (const uint32_t *)((const char *)desc + g.wcnt_off), (const uint32_t *)((const char *)desc + g.wlist_off),
-                       g.k1_wgs, g.blocks_per_wg, G, L, lib, counts, matched, dbg);
+                       g.k1_wgs, g.blocks_per_wg, G, L, lib, counts, matched, dbg, runs ? *runs : none);
 }
 
 void sgc_launch_part_k3(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm,

@@ -235,3 +235,19 @@ bool sgc_build_core_index(const std::vector<uint64_t> &keys, uint32_t L, uint32_
         }
     return true;
 }
+
+uint32_t sgc_rest_filter_log2(uint32_t n_guides) {
+    uint32_t l = 16;
+    while (l < 24 && (1ull << l) < (uint64_t)n_guides * 32) l++;       // <= ~3 % of the bits set per alignment
+    return l;
+}
+
+void sgc_build_rest_filter(const std::vector<uint64_t> &keys, uint32_t cs, uint32_t cl, uint32_t log2_bits, std::vector<uint32_t> &out) {
+    const size_t words = (size_t)1 << (log2_bits - 5);
+    out.assign(3 * words, 0u);
+    for (uint64_t k : keys)
+        for (uint32_t a = 0; a < 3; a++) {
+            const uint32_t idx = sgc_rest_hash(sgc_core_rest(k, cs - a, cl), log2_bits);
+            out[a * words + (idx >> 5)] |= 1u << (idx & 31u);
+        }
+}

@@ -46,6 +46,10 @@ struct sgc_host_core {
 };
 bool sgc_build_core_index(const std::vector<uint64_t> &keys, uint32_t L, uint32_t cs, uint32_t cl, sgc_host_core &out);
 
+// Rest filter of a core (sgc_format.h sgc_core_view::filt): 3 x 2^log2_bits bits, as 32-bit words.
+uint32_t sgc_rest_filter_log2(uint32_t n_guides);
+void sgc_build_rest_filter(const std::vector<uint64_t> &keys, uint32_t cs, uint32_t cl, uint32_t log2_bits, std::vector<uint32_t> &out);
+
 // log2 of the slot count of a single-mismatch table sized for n_children (all 3 L children per guide; load <= 0.5)
 uint32_t sgc_permute_log2_slots(uint64_t n_children);
 
