@@ -80,6 +80,7 @@ struct sgc_ctx {
     uint32_t k1_wgs = 256;      // workgroups of the partition kernel: few, so that few half-empty blocks are left open
     uint64_t max_chunk = 1ull << 27;   // records per internal pass (bounds the scratch buffers)
     bool rest_filter = true;           // core pass A settles "no parent inside the core" with the rest filter (sgc_format.h)
+    bool align_slices = true;          // build the library table with slices that follow the core hash (next sgc_set_library)
     bool host_build = false;           // build the single-mismatch table on the host (sgc_tables.cpp) instead of the GPU
     uint32_t perm_bloom_bits = 8;      // Bloom bits per child of the single-mismatch filter
     // timing
@@ -185,11 +186,11 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
                 // two core passes; k_count_slices itself lays those records out as pass A's runs
                 sgc_core_geometry cg;
                 sgc_core_plan(chunk, c->v_core[0], c->v_core[1], sgc_part_k2_grid(g), &cg);
-                rc = ensure(&c->d_cbuf, &c->cbuf_cap, (size_t)cg.recs_bytes * 2);
+                rc = ensure(&c->d_cbuf, &c->cbuf_cap, (size_t)(cg.runs_a_bytes + cg.fwd_bytes));
                 if (rc) return rc;
                 rc = ensure(&c->d_csmall, &c->csmall_cap, cg.small_bytes);
                 if (rc) return rc;
-                uint64_t *buf0 = (uint64_t *)c->d_cbuf, *buf1 = buf0 + chunk;
+                uint64_t *buf0 = (uint64_t *)c->d_cbuf, *buf1 = (uint64_t *)((char *)c->d_cbuf + cg.runs_a_bytes);
                 void *zeroed = (char *)c->d_desc + g.desc_tail_off;
                 const sgc_runs ra = sgc_core_runs_a(cg, c->v_core[0], c->L, buf0, zeroed, c->d_csmall);
                 { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg, &ra); }
@@ -377,6 +378,7 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
         if (value < 1 || value > (int64_t)0xF0000000ll) return fail(SGC_E_ARG, "max_chunk out of range");
         c->max_chunk = (uint64_t)value; return SGC_OK;
     }
+    if (!strcmp(key, "align_slices")) { c->align_slices = value != 0; return SGC_OK; }       // takes effect at the next sgc_set_library
     if (!strcmp(key, "rest_filter")) { c->rest_filter = value != 0; return SGC_OK; }         // takes effect at the next sgc_set_library
     if (!strcmp(key, "host_build")) { c->host_build = value != 0; return SGC_OK; }          // takes effect at the next sgc_set_library
     if (!strcmp(key, "perm_bloom_bits")) {
@@ -413,7 +415,7 @@ static int upload_table(const sgc_host_table &h, uint64_t **d_slots, uint32_t **
     }
     HIP_TRY(hipStreamSynchronize(st));
     v->slots = *d_slots; v->vals = *d_vals; v->log2_slots = h.log2_slots; v->gid_bits = h.gid_bits;
-    v->log2_slice = h.log2_slice; v->pad_ = 0;
+    v->log2_slice = h.log2_slice; v->core_cl = h.core_cl;
     return SGC_OK;
 }
 
@@ -425,7 +427,8 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
     std::vector<uint64_t> keys;
     sgc_host_table h_lib, h_perm;
     std::string err;
-    int rc = sgc_build_library_table(seqs, n, L, SGC_LDS_LOG2_SLICE, keys, h_lib, err);
+    const uint32_t want_cl = (enable_1mm && c->align_slices && L >= 4 && L <= SGC_REC8_MAXL) ? (L - 2) / 2 : 0;
+    int rc = sgc_build_library_table(seqs, n, L, SGC_LDS_LOG2_SLICE, want_cl, keys, h_lib, err);
     if (rc != SGC_OK) return fail(rc, "sgc_set_library: " + err);
     rc = upload_table(h_lib, &c->d_lib_slots, &c->d_lib_vals, &c->v_lib, c->stream);
     if (rc != SGC_OK) { free_tables(c); return rc; }

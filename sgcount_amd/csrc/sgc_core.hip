@@ -315,17 +315,18 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-// Scratch of the two passes: recs_bytes for each of two record buffers (pass A's runs; pass A's forwarded runs — pass B's
-// runs go to the slice pool, which is dead once k_count_slices has handed its leftovers on), small_bytes for the four
+// Scratch of the two passes: runs_a_bytes (pass A's runs) and fwd_bytes (pass A's forwarded runs) — pass B's runs go to
+// the slice pool, which is dead once k_count_slices has handed its leftovers on —, small_bytes for the four
 // [P][W] matrices, zero_bytes of zeroed words (totals A | totals B | region cursors), which live in the zeroed tail of
 // the descriptor buffer.
-void sgc_core_plan(uint64_t n, const sgc_core_view &a, const sgc_core_view &b, uint32_t producers_a, sgc_core_geometry *g) {
-    g->w = producers_a;
+void sgc_core_plan(uint64_t n, const sgc_core_view &a, const sgc_core_view &b, uint32_t k2_grid, sgc_core_geometry *g) {
+    g->w = k2_grid;
     g->grid_a = g->grid_b = KC_GRID;
-    g->recs_bytes = n * 8;
+    g->runs_a_bytes = n * 8;
+    g->fwd_bytes = n * 8;
     g->zero_bytes = (size_t)(2 * CP_MAXP + 2) * 4;
     static_assert((2 * CP_MAXP + 2) * 4 <= SGC_DESC_TAIL, "the zeroed tail of the descriptor buffer holds the counters");
-    g->mat_a = ((size_t)producers_a << a.log2_p) * 4;          // bytes of ONE matrix of pass A's runs
+    g->mat_a = ((size_t)g->w << a.log2_p) * 4;                 // bytes of ONE matrix of pass A's runs
     g->mat_b = ((size_t)KC_GRID << b.log2_p) * 4;
     g->small_bytes = 2 * g->mat_a + 2 * g->mat_b;
 }

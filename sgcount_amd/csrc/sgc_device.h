@@ -25,7 +25,7 @@ __device__ __forceinline__ bool bucket_resolve(const ulonglong2 &v, uint64_t key
 
 template <bool PACKED>
 __device__ __forceinline__ uint32_t table_find(const sgc_table_view &t, uint64_t key) {
-    uint32_t b = sgc_home_bucket(key, t.log2_slots);
+    uint32_t b = sgc_home_bucket_ex(key, t.log2_slots, t.log2_slice, t.core_cl);
     for (;;) {
         const ulonglong2 v = load_bucket(t, b);
         if (PACKED) {
@@ -51,7 +51,7 @@ __device__ __forceinline__ uint32_t finish_find(const sgc_table_view &t, uint64_
     }
 }
 __device__ __forceinline__ uint32_t bucket_of(const sgc_table_view &t, uint64_t key) {
-    return sgc_home_bucket(key, t.log2_slots);
+    return sgc_home_bucket_ex(key, t.log2_slots, t.log2_slice, t.core_cl);
 }
 
 // One window: exact, then single mismatch.  state: 0 clean, 1 dead, 2+j single 'N' at j.

@@ -73,7 +73,9 @@ struct sgc_table_view {
     uint32_t log2_slots;
     uint32_t gid_bits;       // 0 => split layout
     uint32_t log2_slice;
-    uint32_t pad_;
+    uint32_t core_cl;        // 0: the slice is the top of the full-key hash.  > 0: the slice is picked by the hash of key bases
+                             // [1, 1 + core_cl) alone (sgc_home_bucket_ex): the same bases, hashed the same way, pick the
+                             // partition of core pass A, so a slice's leftovers fall into a handful of that pass's partitions
 };
 
 SGC_HD uint32_t sgc_home_bucket(uint64_t key, uint32_t log2_slots) { return (uint32_t)(sgc_hash(key) >> (65 - log2_slots)); }
@@ -120,13 +122,20 @@ struct sgc_core_view {
     const uint32_t *filt;
 };
 SGC_HD uint32_t sgc_rest_hash(uint32_t rest, uint32_t log2_bits) { return (rest * 0x9E3779B1u) >> (32 - log2_bits); }
-// 32-bit hash of a core value (<= 28 bits): its top bits pick the partition, the next ones the bucket
-SGC_HD uint32_t sgc_core_hash(uint32_t corev) {
-    uint32_t h = corev * 0x9E3779B1u;
-    h ^= h >> 16;
-    return h * 0x85EBCA6Bu;
-}
+// 32-bit hash of a core value (<= 28 bits): its top bits pick the partition, the next ones the bucket.  One multiply
+// (Fibonacci hashing): the partition kernel evaluates it for every read, and 32-bit multiplies run at quarter rate.
+SGC_HD uint32_t sgc_core_hash(uint32_t corev) { return corev * 0x9E3779B1u; }
+// 32-bit hash of a whole key, for the bucket inside a core-hashed slice (one multiply instead of the 64-bit sgc_hash)
+SGC_HD uint32_t sgc_hash32(uint64_t key) { return (uint32_t)(key ^ (key >> 29)) * 0x85EBCA6Bu; }
 SGC_HD uint32_t sgc_core_part(uint32_t h, uint32_t log2_p) { return log2_p ? h >> (32 - log2_p) : 0u; }
+// Home bucket of a key in a sliced table whose slices follow the core hash (sgc_table_view::core_cl): slice = the top
+// bits of the hash of key bases [1, 1 + core_cl) (= span bases [2, 2 + core_cl): core A as the Centered window sees
+// it), bucket inside the slice = the top bits of the full-key hash.
+SGC_HD uint32_t sgc_home_bucket_ex(uint64_t key, uint32_t log2_slots, uint32_t log2_slice, uint32_t core_cl) {
+    if (core_cl == 0 || log2_slice >= log2_slots) return sgc_home_bucket(key, log2_slots);
+    const uint32_t hc = sgc_core_hash((uint32_t)((key >> 2) & ((1ull << (2 * core_cl)) - 1ull)));
+    return (sgc_core_part(hc, log2_slots - log2_slice) << (log2_slice - 1)) | (sgc_hash32(key) >> (33 - log2_slice));
+}
 SGC_HD uint32_t sgc_core_home(uint32_t h, uint32_t log2_p) {
     return (h >> (32 - log2_p - SGC_CORE_LOG2_S)) & ((1u << SGC_CORE_LOG2_S) - 1u);
 }

@@ -64,12 +64,12 @@ void sgc_launch_part_k4(hipStream_t st, uint32_t n_guides, const sgc_part_geomet
 
 // ---- single-mismatch resolution in LDS (sgc_core.hip) -------------------------------------------
 struct sgc_core_geometry {
-    uint32_t w, grid_a, grid_b, pad_;       // w: producer workgroups of pass A's runs (the grid of k_count_slices)
-    uint64_t recs_bytes, zero_bytes, small_bytes, mat_a, mat_b;
+    uint32_t w, grid_a, grid_b, pad_;       // w: producers of pass A's runs (the grid of k_count_slices)
+    uint64_t runs_a_bytes, fwd_bytes, zero_bytes, small_bytes, mat_a, mat_b;
 };
-void sgc_core_plan(uint64_t n, const sgc_core_view &a, const sgc_core_view &b, uint32_t producers_a, sgc_core_geometry *g);
-// buf0/buf1: recs_bytes each (pass A's runs, pass A's forwarded runs); buf2: recs_bytes, pass B's runs (the slice pool may
-// serve: it is dead by then); zeroed: zero_bytes of zeros (stream-ordered before k_count_slices); small: small_bytes
+void sgc_core_plan(uint64_t n, const sgc_core_view &a, const sgc_core_view &b, uint32_t k2_grid, sgc_core_geometry *g);
+// buf0: runs_a_bytes (pass A's runs); buf1: fwd_bytes (pass A's forwarded runs); buf2: >= fwd_bytes, pass B's runs (the slice
+// pool may serve: it is dead by then); zeroed: zero_bytes of zeros (stream-ordered before k_count_slices); small: small_bytes
 sgc_runs sgc_core_runs_a(const sgc_core_geometry &g, const sgc_core_view &ca, uint32_t L, uint64_t *buf0, void *zeroed, void *small);
 // pass: 0 = core A (reads buf0, forwards through buf1 into buf2), 1 = core B (reads buf2)
 void sgc_launch_core(hipStream_t st, int pass, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm,

@@ -54,10 +54,12 @@ static_assert(PART_TILE % PART_BLOCK == 0 || PART_BLOCK % PART_TILE == 0, "tile/
 __device__ __forceinline__ uint32_t part_front(uint32_t b) { return ((b * 2654435761u) >> 26) << 4; }      // 64 starts, 128-B aligned
 #define PART_TAG_SHIFT 53u
 #define PART_TAG_MASK ((1ull << PART_TAG_SHIFT) - 1ull)
+// With slices that follow the core hash (sgc_table_view::core_cl, sgc_home_bucket_ex) a slice's misses fall into the few
+// partitions of core pass A that refine it, so the epilogue of k_count_slices writes a handful of streams, not hundreds.
 __device__ __forceinline__ uint32_t part_of(uint64_t &rec, uint64_t kmask, uint32_t sh, uint32_t log2_slots,
-                                            uint32_t log2_slice) {
+                                            uint32_t log2_slice, uint32_t core_cl) {
     if ((rec >> sh) != 0) return 1u << (log2_slots - log2_slice);
-    const uint32_t hb = sgc_home_bucket((rec >> 2) & kmask, log2_slots);
+    const uint32_t hb = sgc_home_bucket_ex((rec >> 2) & kmask, log2_slots, log2_slice, core_cl);
     rec |= (uint64_t)(hb & ((1u << (log2_slice - 1)) - 1u)) << PART_TAG_SHIFT;
     return hb >> (log2_slice - 1);
 }
@@ -65,7 +67,7 @@ __device__ __forceinline__ uint32_t part_of(uint64_t &rec, uint64_t kmask, uint3
 // ------------------------------------------------------------------------------------------------ K1
 __global__ void __launch_bounds__(K1_THREADS) k_partition(const uint64_t *__restrict__ recs, uint64_t n, uint64_t per_wg,
                                                    uint32_t blocks_per_wg, uint32_t L, uint32_t log2_slots,
-                                                   uint32_t log2_slice, uint64_t *__restrict__ pool,
+                                                   uint32_t log2_slice, uint32_t core_cl, uint64_t *__restrict__ pool,
                                                    uint32_t *__restrict__ desc, uint32_t *__restrict__ tail,
                                                    uint32_t tail_words, uint32_t *__restrict__ wcnt,
                                                    uint32_t *__restrict__ wlist) {
@@ -108,7 +110,7 @@ __global__ void __launch_bounds__(K1_THREADS) k_partition(const uint64_t *__rest
         for (uint32_t k = 0; k < PART_TILE / K1_THREADS; k++) {
             const uint32_t j = k * K1_THREADS + t;
             if (j < m) {
-                const uint32_t p = part_of(rec[k], kmask, sh, log2_slots, log2_slice);
+                const uint32_t p = part_of(rec[k], kmask, sh, log2_slots, log2_slice, core_cl);
                 pr[k] = (p << 16) | atomicAdd(&cnt[p], 1u);
             }
         }
@@ -358,8 +360,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     // Epilogue (sgc_runs.h): what this workgroup could not settle — the misses it compacted to the fronts of its blocks —
     // and its share of the generic partition's blocks (records with an 'N' or a dead window: nothing to probe here) go to
     // core pass A, laid out by that pass's partitions in a region of ep.recs of the workgroup's own.  Two sweeps over the
-    // same records (L2-warm: just written): histogram, then placement.  The fronts of a window of blocks are walked as ONE
-    // flat range (prefix of the fills in LDS, a branch-free search per record), four loads in flight per lane.
+    // same records: histogram, then placement.
     const uint32_t Pg = 1u << (lib.log2_slots - lib.log2_slice);                       // index of the generic partition
     uint32_t Bg;
     preg[t] = wg_scan_1024(t < k1_wgs ? wcnt[t * PART_ARR + Pg] : 0u, wtmp, &Bg);
@@ -692,7 +693,7 @@ void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_
 void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib,
                         const sgc_part_geometry &g, uint64_t *pool, uint32_t *desc) {
     hipLaunchKernelGGL(k_partition, dim3(g.k1_wgs), dim3(K1_THREADS), 0, st, recs, n, g.per_wg, g.blocks_per_wg, L,
-                       lib.log2_slots, lib.log2_slice, pool, desc, (uint32_t *)((char *)desc + g.desc_tail_off), SGC_DESC_TAIL / 4,
+                       lib.log2_slots, lib.log2_slice, lib.core_cl, pool, desc, (uint32_t *)((char *)desc + g.desc_tail_off), SGC_DESC_TAIL / 4,
                        (uint32_t *)((char *)desc + g.wcnt_off), (uint32_t *)((char *)desc + g.wlist_off));
 }
 

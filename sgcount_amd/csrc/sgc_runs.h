@@ -24,7 +24,7 @@ struct sgc_runs {
     uint32_t *off;         // [P][W]: index in recs where they start
     uint32_t *tot;         // [P]: sum over w of cnt (zeroed before the producers start)
     uint32_t *cursor;      // bump allocator over recs (zeroed before the producers start)
-    uint32_t W;            // number of producer workgroups (<= 1024)
+    uint32_t W;            // number of producer workgroups (<= 1024): columns of the matrices
     // partition function of the consuming pass: hash of the record's core bases, or RUN_DROP for a record whose
     // three windows are all dead (a read too short for the Centered window, src/counter.rs:158-166: it cannot match,
     // and all such records are identical, so they would pile up in one partition)

@@ -35,7 +35,7 @@ static void table_alloc(sgc_host_table &t, uint64_t entries, double max_load, ui
 }
 
 static inline void table_insert(sgc_host_table &t, uint64_t key, uint32_t gid) {
-    uint32_t b = sgc_home_bucket(key, t.log2_slots);
+    uint32_t b = sgc_home_bucket_ex(key, t.log2_slots, t.log2_slice, t.core_cl);
     for (;;) {
         for (uint32_t k = 0; k < 2; k++) {
             const uint64_t h = 2ull * b + k;
@@ -50,7 +50,7 @@ static inline void table_insert(sgc_host_table &t, uint64_t key, uint32_t gid) {
 }
 
 static inline uint32_t table_find_host(const sgc_host_table &t, uint64_t key) {
-    uint32_t b = sgc_home_bucket(key, t.log2_slots);
+    uint32_t b = sgc_home_bucket_ex(key, t.log2_slots, t.log2_slice, t.core_cl);
     for (;;) {
         for (uint32_t k = 0; k < 2; k++) {
             const uint64_t h = 2ull * b + k;
@@ -74,16 +74,16 @@ static uint32_t choose_gid_bits(uint32_t n, uint32_t L) {
 }
 
 // true if some slice is filled beyond `limit` of its slots (probing must always find a free slot)
-static bool slice_overfull(const std::vector<uint64_t> &keys, uint32_t log2_slots, uint32_t log2_slice, double limit) {
+static bool slice_overfull(const std::vector<uint64_t> &keys, uint32_t log2_slots, uint32_t log2_slice, uint32_t core_cl, double limit) {
     if (log2_slice >= log2_slots) return false;
     std::vector<uint32_t> fill(1ull << (log2_slots - log2_slice), 0);
     const uint32_t cap = (uint32_t)((double)(1u << log2_slice) * limit);
     for (uint64_t k : keys)
-        if (++fill[sgc_slice_of(k, log2_slots, log2_slice)] > cap) return true;
+        if (++fill[sgc_home_bucket_ex(k, log2_slots, log2_slice, core_cl) >> (log2_slice - 1)] > cap) return true;
     return false;
 }
 
-int sgc_build_library_table(const uint8_t *seqs, uint32_t n, uint32_t L, uint32_t max_log2_slice,
+int sgc_build_library_table(const uint8_t *seqs, uint32_t n, uint32_t L, uint32_t max_log2_slice, uint32_t core_cl,
                             std::vector<uint64_t> &keys, sgc_host_table &out, std::string &err) {
     if (L == 0 || L > SGC_MAXL) { err = "guide length " + std::to_string(L) + " outside 1.." + std::to_string(SGC_MAXL); return SGC_E_UNSUPPORTED; }
     if (n == 0) { err = "empty library"; return SGC_E_ARG; }
@@ -94,14 +94,23 @@ int sgc_build_library_table(const uint8_t *seqs, uint32_t n, uint32_t L, uint32_
             return SGC_E_UNSUPPORTED;
         }
     }
-    // grow the table until no slice is more than 60 % full (hash imbalance between slices)
-    uint32_t extra = 0;
-    for (;; extra++) {
-        table_alloc(out, n, 0.4, choose_gid_bits(n, L), max_log2_slice, extra);
-        if (extra >= 4 || !slice_overfull(keys, out.log2_slots, out.log2_slice, 0.6)) break;
+    // grow the table until no slice is more than 60 % full (hash imbalance between slices); slices that follow the core
+    // hash are tried first (once, without growing: guides that share those bases do not spread however large the table)
+    if (core_cl && 2 * (1 + core_cl) > 2 * L) core_cl = 0;
+    out.core_cl = 0;
+    if (core_cl) {
+        table_alloc(out, n, 0.4, choose_gid_bits(n, L), max_log2_slice, 0);
+        if (out.log2_slice < out.log2_slots && !slice_overfull(keys, out.log2_slots, out.log2_slice, core_cl, 0.6)) out.core_cl = core_cl;
     }
-    if (slice_overfull(keys, out.log2_slots, out.log2_slice, 0.9)) {   // pathological key set: give up slicing
-        table_alloc(out, n, 0.4, choose_gid_bits(n, L), 0, 0);
+    if (!out.core_cl) {
+        uint32_t extra = 0;
+        for (;; extra++) {
+            table_alloc(out, n, 0.4, choose_gid_bits(n, L), max_log2_slice, extra);
+            if (extra >= 4 || !slice_overfull(keys, out.log2_slots, out.log2_slice, 0, 0.6)) break;
+        }
+        if (slice_overfull(keys, out.log2_slots, out.log2_slice, 0, 0.9)) {   // pathological key set: give up slicing
+            table_alloc(out, n, 0.4, choose_gid_bits(n, L), 0, 0);
+        }
     }
     for (uint32_t i = 0; i < n; i++) {
         if (table_find_host(out, keys[i]) != SGC_NONE) {      // src/library.rs:91-96

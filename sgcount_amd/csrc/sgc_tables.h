@@ -13,6 +13,7 @@ struct sgc_host_table {
     uint32_t log2_slots = 0;
     uint32_t gid_bits = 0;        // 0 => split layout
     uint32_t log2_slice = 0;      // probing wraps inside slices of 2^log2_slice slots
+    uint32_t core_cl = 0;         // slices follow the core hash (sgc_format.h sgc_home_bucket_ex); 0 = full-key hash
     uint64_t entries = 0;
 };
 
@@ -22,7 +23,9 @@ bool sgc_pack_key(const uint8_t *seq, uint32_t L, uint64_t &key);
 // Library::table_from_reader (reference src/library.rs:89-99).  Returns 0, or SGC_E_DUPLICATE /
 // SGC_E_UNSUPPORTED (include/sgcount_hip.h) with `err` set.
 // max_log2_slice bounds the slice size (the LDS budget of the partitioned path); 0 = unpartitioned.
-int sgc_build_library_table(const uint8_t *seqs, uint32_t n, uint32_t L, uint32_t max_log2_slice,
+// core_cl > 0 asks for slices that follow the core hash; a key set that does not spread that way (guides sharing
+// those bases) gets full-key-hash slices instead (out.core_cl says which).
+int sgc_build_library_table(const uint8_t *seqs, uint32_t n, uint32_t L, uint32_t max_log2_slice, uint32_t core_cl,
                             std::vector<uint64_t> &keys, sgc_host_table &out, std::string &err);
 
 // Permuter::build (reference src/permutes.rs:63-75,127-158) restricted to what Counter::assign can

@@ -24,7 +24,7 @@ class DeviceWorkload:
 
     def __init__(self, n_reads, n_guides=100_000, L=20, one_mismatch=True, position_recursion=True, offset=30,
                  reads_seed=synth.READS_SEED, lib_seed=synth.LIB_SEED, mode=synth.MODE_FIXED, device_index=0,
-                 gen_chunk=8_000_000, reverse=False):
+                 gen_chunk=8_000_000, reverse=False, lib_options=None):
         import torch
         self.torch = torch
         self.n_reads, self.n_guides, self.L = int(n_reads), n_guides, L
@@ -33,7 +33,7 @@ class DeviceWorkload:
         self.dev = torch.device("cuda", device_index)
         torch.cuda.set_device(self.dev)
         self.lib_seqs, self.library = synth_library(n_guides, L, lib_seed)
-        self.dl = self.library.device(one_mismatch, device_index)
+        self.dl = self.library.device(one_mismatch, device_index, lib_options)
         self.abi = self.dl.lib
         self.dl.set_stream(torch.cuda.current_stream().cuda_stream)
         self.words = self.dl.record_bytes // 8

@@ -27,10 +27,12 @@ def main():
     ap.add_argument("--nocheck", action="store_true")
     ap.add_argument("--notiming", action="store_true", help="leave the library's per-kernel events off (wall time only)")
     ap.add_argument("--opts", default="", help="extra options k=v,k=v applied to all variants")
+    ap.add_argument("--lib-opts", default="", help="options k=v,k=v applied BEFORE the tables are built (align_slices, rest_filter, ...)")
     args = ap.parse_args()
     import torch
     from sgcount_amd.workload import DeviceWorkload
-    wl = DeviceWorkload(args.reads, args.guides, 20, one_mismatch=args.workload == "1mm")
+    lib_opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in filter(None, args.lib_opts.split(","))}
+    wl = DeviceWorkload(args.reads, args.guides, 20, one_mismatch=args.workload == "1mm", lib_options=lib_opts)
     for kv in filter(None, args.opts.split(",")):
         k, v = kv.split("=")
         wl.dl.set_option(k, int(v))
