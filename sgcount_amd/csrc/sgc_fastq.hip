@@ -143,7 +143,7 @@ struct fq_args {
 };
 
 template <bool REC16>
-__global__ void __launch_bounds__(FQ_THREADS) k_fastq_pack(const fq_args a) {
+__global__ void __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_num_sgpr(80))) k_fastq_pack(const fq_args a) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[FQ_TILE + FQ_HALO_MAX];
     __shared__ __attribute__((aligned(8))) uint16_t masks[FQ_PIECES];      // newline mask of every 16-byte piece
     __shared__ uint32_t list[FQ_CAP], wtmp[17];

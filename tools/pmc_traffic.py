@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turns rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py into profiles/pmc_traffic.json.
 
-    python tools/pmc_traffic.py <fetch_dir_1mm> <write_dir_1mm> <fetch_dir_exact> <write_dir_exact>
+    python tools/pmc_traffic.py <fetch_dir_1mm> <write_dir_1mm> <fetch_dir_exact> <write_dir_exact> [round-label]
 
 FETCH_SIZE / WRITE_SIZE are in KiB.  MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE reads exactly half the bytes
 of a wide coalesced streaming read (128-B requests tallied at 64 B); other access widths are uncalibrated, so
@@ -47,6 +47,7 @@ def main():
             kern[k] = {"fetch_bytes_raw": fetch[k] * 1024.0, "fetch_bytes_corrected": rb, "write_bytes": wb}
             tot += rb + wb
         out[w] = {"hbm_bytes_per_step": tot, "bytes_per_read": tot / n_reads, "fetch_correction": cal,
+                  "collected": "profiles/%s" % (sys.argv[5] if len(sys.argv) > 5 else "?"),
                   "unit": "bytes per 100M-read pass (FETCH_SIZE x correction + WRITE_SIZE)", "kernels": kern}
     json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
                                      "pmc_traffic.json"), "w"), indent=1)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times the on-device ingest paths on synthetic data resident in HBM:
    raw reads (bytes + offsets) -> records   (sgc_pack_reads_device)
-   FASTQ text                  -> records   (sgc_sample_push_fastq: pass A + scan + pass B)
+   FASTQ text                  -> records   (sgc_sample_push_fastq_part: k_fastq_count + k_scan_tiles + k_fastq_pack)
 and the whole FASTQ -> counts path.  python tools/tune_ingest.py --reads 20000000"""
 import argparse
 import ctypes as C
@@ -41,13 +41,14 @@ def main():
                 tot_bytes += raw.numel(); tot_ms += t.pack_ms
             else:
                 fq, _ = synth.fastq_device(lib_dev, first, m)
+                n_nl = int((fq == 10).sum().item())
                 for rep in range(3):
                     _ffi.check(dl.lib.sgc_sample_reset(smp))
                     dl.timing(reset=True)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                     n = C.c_uint64(0)
-                    _ffi.check(dl.lib.sgc_sample_push_fastq(smp, fq.data_ptr(), fq.numel(), _ffi.MEM_DEVICE, C.byref(n)))
+                    _ffi.check(dl.lib.sgc_sample_push_fastq_part(smp, fq.data_ptr(), fq.numel(), _ffi.MEM_DEVICE, 0, n_nl, C.byref(n)))
                     e1.record()
                     torch.cuda.synchronize()
                     t = dl.timing(reset=True)
