@@ -8,6 +8,15 @@
  * FNV map here), one pass over records, a window copy per probe, an id-keyed
  * result map.  It is single-threaded because the reference is single-threaded
  * within a sample (count.rs:117-118 parallelises across samples only).
+ *
+ * PINNED by the reference's own unit-test vectors (counter.rs:283-382,
+ * permutes.rs:193-253, library.rs:119-136, offsetter.rs:249-362: tests/test_oracle_kat.py)
+ * and by the reference's example/ files through their read names
+ * (tests/test_oracle_fixtures.py).  NOT pinned (no upstream test, third-party
+ * fxread ^0.2.5 — DESIGN.md §2): Offset::Reverse on non-ACGT bytes, and two
+ * reader decisions taken here and shared with the product's readers: a '\r'
+ * before the '\n' belongs to the line terminator, and a FASTQ header without
+ * '@' / separator without '+' is a malformed record (ORC_E_FORMAT).
  */
 #include "sgcount_oracle.h"
 
