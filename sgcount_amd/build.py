@@ -52,7 +52,8 @@ def build_one(so, force=False, verbose=False):
         return so
     srcs, _ = TARGETS[so]
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-result", "-Wno-unused-value", "-o", so] + [os.path.join(CSRC, f) for f in srcs]
+           "-Wno-unused-result", "-Wno-unused-value"] + os.environ.get("SGC_HIPCC_FLAGS", "").split() + \
+          ["-o", so] + [os.path.join(CSRC, f) for f in srcs]      # SGC_HIPCC_FLAGS: e.g. -DSGC_STAMPS=1 (tools/evidence.sh)
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

@@ -38,6 +38,12 @@
 #include "sgc_kernels.h"
 #include "sgc_runs.h"
 
+// s_memtime phase stamps + printf (dbg 512): compiled in only with -DSGC_STAMPS=1 (tools/evidence.sh builds such a library for
+// profiles/*/stamps.txt); in the shipped kernels they would cost scalar registers the hot loops do not have
+#ifndef SGC_STAMPS
+#define SGC_STAMPS 0
+#endif
+
 #define CP_MAXP RUN_MAXP
 #define KC_THREADS 1024u
 #define KC_CHUNK 4096u           // records per unit of resolver work
@@ -146,7 +152,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
         for (uint32_t i0 = lo; i0 < hi; i0 += KC_THREADS) {
             const bool valid = i0 + t < hi;
             unsigned long long tsa = 0;
-            if (dbg & 512) { tsa = __builtin_amdgcn_s_memtime(); n_it++; }
+            if (SGC_STAMPS && (dbg & 512)) { tsa = __builtin_amdgcn_s_memtime(); n_it++; }
             const uint64_t rec = r0;
             r0 = r1; r1 = r2; r2 = r3;
             const uint64_t span = rec & smask;
@@ -172,7 +178,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 if (st1 >= 2) { const uint32_t j = st1 - 2; if (j >= ll1 && j < ll1 + cl) { vis &= ~2u; unk |= 2u; } else nr1 = 1u << (2 * (j < ll1 ? j : j - cl)); }
                 if (st2 >= 2) { const uint32_t j = st2 - 2; if (j >= ll2 && j < ll2 + cl) { vis &= ~4u; unk |= 4u; } else nr2 = 1u << (2 * (j < ll2 ? j : j - cl)); }
             }
-            if (dbg & 512) { const unsigned long long x = __builtin_amdgcn_s_memtime(); ts_unp += x - tsa; tsa = x; }
+            if (SGC_STAMPS && (dbg & 512)) { const unsigned long long x = __builtin_amdgcn_s_memtime(); ts_unp += x - tsa; tsa = x; }
             uint32_t ex0 = SGC_NONE, ex1 = SGC_NONE, ex2 = SGC_NONE;      // entry of the exact guide
             uint32_t cc = 0;                                              // visible distance-1 guides, 8 bits per window
             uint32_t k0 = 0, k1 = 0, k2 = 0;                              // entry of the (last) one
@@ -196,7 +202,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                     }
                 }
             }
-            if (dbg & 512) { const unsigned long long x = __builtin_amdgcn_s_memtime(); ts_scan += x - tsa; tsa = x; }
+            if (SGC_STAMPS && (dbg & 512)) { const unsigned long long x = __builtin_amdgcn_s_memtime(); ts_scan += x - tsa; tsa = x; }
             // Levels in the reference's order, as bits: 0 C-exact, 1 C-1mm, 2 P-exact, 3 P-1mm, 4 M-exact, 5 M-1mm.
             // lm: the level holds on what this pass sees (1mm: exactly one visible parent; invisible windows
             // found nothing).  um: the 1mm level cannot be decided here (a clean visible window with no
@@ -235,7 +241,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 if (cand & 8u) { const uint32_t x = sgc_rest_hash(R2, cv.filt_log2); if (!((cv.filt[2u * fw + (x >> 5)] >> (x & 31u)) & 1u)) unk_above &= ~8u; }
                 if (cand & 32u) { const uint32_t x = sgc_rest_hash(R0, cv.filt_log2); if (!((cv.filt[x >> 5] >> (x & 31u)) & 1u)) unk_above &= ~32u; }
             }
-            if (dbg & 512) { const unsigned long long x = __builtin_amdgcn_s_memtime(); ts_dec += x - tsa; tsa = x; }
+            if (SGC_STAMPS && (dbg & 512)) { const unsigned long long x = __builtin_amdgcn_s_memtime(); ts_dec += x - tsa; tsa = x; }
             bool fwd_it = false;
             if (valid) {
                 if (FINAL || unk_above == 0) {
@@ -280,10 +286,10 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                     }
                 }
             }
-            if (dbg & 512) { const unsigned long long x = __builtin_amdgcn_s_memtime(); ts_out += x - tsa; }
+            if (SGC_STAMPS && (dbg & 512)) { const unsigned long long x = __builtin_amdgcn_s_memtime(); ts_out += x - tsa; }
         }
     }
-    if ((dbg & 512) && (t & 63) == 0 && (blockIdx.x % 101) == 0 && (t >> 6) < 2)
+    if ((SGC_STAMPS && (dbg & 512)) && (t & 63) == 0 && (blockIdx.x % 101) == 0 && (t >> 6) < 2)
         printf("k_core<%d> wg %u wave %u: %u iters, load+unpack %llu scan %llu decide %llu out %llu total %llu ticks\n", (int)FINAL,
                blockIdx.x, t >> 6, n_it, ts_unp, ts_scan, ts_dec, ts_out, (unsigned long long)(__builtin_amdgcn_s_memtime() - ts_begin));
     __syncthreads();

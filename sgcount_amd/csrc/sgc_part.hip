@@ -29,6 +29,12 @@
 #include "sgc_kernels.h"
 #include "sgc_runs.h"
 
+// s_memtime phase stamps + printf (dbg 512): compiled in only with -DSGC_STAMPS=1 (tools/evidence.sh builds such a library for
+// profiles/*/stamps.txt); in the shipped kernels they would cost scalar registers the hot loops do not have
+#ifndef SGC_STAMPS
+#define SGC_STAMPS 0
+#endif
+
 #ifndef K1_THREADS
 #define K1_THREADS 1024u        // one 16-wave workgroup per CU: few workgroups leave few half-empty blocks open
 #endif
@@ -235,10 +241,10 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     for (uint32_t i = t; i < S; i += K2_THREADS) cnt[i] = 0;
     for (uint32_t i = t; i < RUN_MAXP; i += K2_THREADS) hn[i] = 0;
     if (t < 2 * K2_U) miss_cnt[t / K2_U][t % K2_U] = 0;
-    // diagnostic stamps (dbg & 512): cycle counts of the phases of a few workgroups, printed at the end
+    // diagnostic stamps (SGC_STAMPS && (dbg & 512)): cycle counts of the phases of a few workgroups, printed at the end
     unsigned long long ts0 = 0, ts_scan = 0, ts_loop = 0;
     uint32_t n_groups_dbg = 0;
-    if (dbg & 512) ts0 = __builtin_amdgcn_s_memtime();
+    if (SGC_STAMPS && (dbg & 512)) ts0 = __builtin_amdgcn_s_memtime();
     // K1 workgroup w handed this partition wcnt[w][p] blocks, listed in wlist[w][p][]: in that order (w major) the
     // partition's blocks form one sequence, of which this workgroup takes the g-th of G equal shares — no scan of
     // the descriptors, and shares that differ by at most one block.
@@ -255,7 +261,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             list[i] = (b << 11) | ((desc[b] & DESC_FILL_MASK) - 1u);
         }
         __syncthreads();
-        if (dbg & 512) { ts_scan += __builtin_amdgcn_s_memtime() - ts0; ts0 = __builtin_amdgcn_s_memtime(); n_groups_dbg += (nl + K2_U - 1) / K2_U; }
+        if (SGC_STAMPS && (dbg & 512)) { ts_scan += __builtin_amdgcn_s_memtime() - ts0; ts0 = __builtin_amdgcn_s_memtime(); n_groups_dbg += (nl + K2_U - 1) / K2_U; }
         // software pipeline over groups of K2_U blocks: `cur` is processed while `nxt` is in flight.  Block ids and
         // fills are wave-uniform (scalar registers).
         uint64_t cur[Q], nxt[Q];
@@ -336,9 +342,9 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             }
         }
         __syncthreads();
-        if (dbg & 512) { ts_loop += __builtin_amdgcn_s_memtime() - ts0; ts0 = __builtin_amdgcn_s_memtime(); }
+        if (SGC_STAMPS && (dbg & 512)) { ts_loop += __builtin_amdgcn_s_memtime() - ts0; ts0 = __builtin_amdgcn_s_memtime(); }
     }
-    if ((dbg & 512) && t == 0 && (blockIdx.x % 97) == 0)
+    if ((SGC_STAMPS && (dbg & 512)) && t == 0 && (blockIdx.x % 97) == 0)
         printf("K2 wg %u slice %u: scan %llu loop %llu cycles, %u groups\n", blockIdx.x, p, ts_scan, ts_loop, n_groups_dbg);
     // flush the slot counters: one atomic per occupied slot
     uint64_t local = 0;

@@ -29,6 +29,9 @@ for GROUP in "SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAV
   rocprofv3 --kernel-trace --pmc $GROUP --output-format csv -d $D/sq$i -- python3 $R/tools/tune.py --variants 4 --rounds 1 --steps 1 > $D/sq$i.log 2>&1 || { echo "counter group $i failed" >> $D/sq_errors.txt; continue; }
   (cd $R && python3 tools/pmc_table.py $(ls -t $D/sq$i/*/*counter_collection.csv | head -1) k_count_slices k_core k_partition k_export) > $D/sq_$i.txt
 done
-cd $R && python3 tools/tune.py --variants "4:dbg=512" --rounds 1 --steps 1 --nocheck 2>&1 | grep -E "^K2 wg|^k_core" > $D/stamps.txt
+# the phase stamps are compiled out of the shipped kernels (they cost scalar registers): rebuild with them for this step only
+cd $R && SGC_HIPCC_FLAGS=-DSGC_STAMPS=1 python3 -c "from sgcount_amd import build as b; b.build_one(b.SO, force=True)" &&
+python3 tools/tune.py --variants "4:dbg=512" --rounds 1 --steps 1 --nocheck 2>&1 | grep -E "^K2 wg|^k_core" > $D/stamps.txt
+python3 -c "from sgcount_amd import build as b; b.build_one(b.SO, force=True)"
 rm -rf $D/prof_* $D/pmc_fetch_* $D/pmc_write_* $D/sq[0-9] 2>/dev/null
 ls -la $D
