@@ -739,7 +739,7 @@ static int push_fastq_part(sgc_sample *s, const uint8_t *text, uint64_t n_bytes,
     {
         timed t(c, T_PACK, true);
         sgc_launch_fastq_pack(c->stream, d_text, n_bytes, tile_scratch, first_line, (uint32_t)n_newlines, (uint32_t)lines, c->L, c->rec16,
-                              s->reverse, s->offset, s->recursion, c->d_recs, s->d_err);
+                              s->reverse, s->offset, s->recursion, c->d_recs, s->d_err, (c->dbg >> 24) & 3u);
     }
     HIP_TRY(hipGetLastError());
     if (slot >= 0) { HIP_TRY(hipEventRecord(c->ev_use[slot], c->stream)); c->use_recorded[slot] = true; }

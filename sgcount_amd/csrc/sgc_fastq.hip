@@ -128,6 +128,55 @@ __device__ __forceinline__ uint32_t find_nl_bwd(const uint64_t *m64, uint32_t a,
     }
 }
 
+
+// Four lanes per read: lane `sub` (0..3) classifies span bases w = sub, sub + 4, ... of the read at s[0, n) and the
+// partial results are merged with two butterfly steps inside the quad — the same bits as sgc_pack_one (sgc_format.h),
+// in a quarter of the serial steps.  All four lanes return the merged (span, status).  `valid` = the quad has a read.
+template <class Ptr>
+__device__ __forceinline__ void pack_quad(Ptr s, uint32_t n, bool valid, uint32_t sub, uint32_t L, int reverse, uint32_t o, int recursion,
+                                          uint64_t &span, uint64_t &status) {
+    const uint32_t K = L + 2;
+    const bool c_ok = valid && o + L <= n;
+    const bool p_ok = c_ok && recursion && (o + 1 + L <= n);
+    const bool m_ok = p_ok && o >= 1;
+    uint32_t lo = 0, hi = 0;          // span bits
+    uint32_t cnt = 0;                 // invalid bases per window: M | C << 8 | P << 16; "bad" (non-ACGT, non-N) flags at bits 24..26
+    uint32_t npos = 0;                // 2 + window position of an 'N', per window, 8 bits each
+    if (c_ok) {
+        for (uint32_t w = sub; w < K; w += 4) {
+            const int32_t p = (int32_t)o - 1 + (int32_t)w;
+            if (p < 0 || (uint32_t)p >= n) continue;      // only reachable for windows already out of bounds
+            const uint8_t b = reverse ? s[n - 1 - (uint32_t)p] : s[p];
+            const uint32_t code = reverse ? sgc_base_code_rc(b) : sgc_base_code(b);
+            if (code < 4) { if (w < 16) lo |= code << (2 * w); else hi |= code << (2 * (w - 16)); continue; }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {                 // span base w sits at window position w (M), w-1 (C), w-2 (P)
+                const int32_t j = (int32_t)w - k;
+                if (j < 0 || j >= (int32_t)L) continue;
+                cnt += 1u << (8 * k);
+                if (code == 4) npos |= (2u + (uint32_t)j) << (8 * k); else cnt |= 1u << (24 + k);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 1; m <= 2; m <<= 1) {
+        lo |= __shfl_xor(lo, m, 64); hi |= __shfl_xor(hi, m, 64); npos |= __shfl_xor(npos, m, 64);
+        const uint32_t oc = __shfl_xor(cnt, m, 64);
+        cnt = ((cnt & 0x00FFFFFFu) + (oc & 0x00FFFFFFu)) | ((cnt | oc) & 0x07000000u);
+    }
+    span = c_ok ? ((uint64_t)lo | ((uint64_t)hi << 32)) : 0ull;
+    const bool ok[3] = {m_ok, c_ok, p_ok};
+    uint32_t st[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint32_t ninv = (cnt >> (8 * k)) & 0xFFu;
+        if (!ok[k] || ninv >= 2 || ((cnt >> (24 + k)) & 1u)) st[k] = SGC_STATE_DEAD;
+        else if (ninv == 0) st[k] = SGC_STATE_CLEAN;
+        else st[k] = (npos >> (8 * k)) & 0xFFu;
+    }
+    status = (uint64_t)st[1] + (uint64_t)K * ((uint64_t)st[2] + (uint64_t)K * (uint64_t)st[0]);
+}
+
 struct fq_args {
     const uint8_t *text;          // the part: whole lines
     uint64_t n;                   // its bytes
@@ -140,10 +189,11 @@ struct fq_args {
                                   // exactly the sequence lines among them, and nothing beyond is ever written
     uint32_t L, o, halo;          // halo: bytes staged beyond the tile, multiple of 64, <= FQ_HALO_MAX
     int reverse, recursion;
+    uint32_t dbg;                 // timing-only ablations (results wrong): 1 = no packing, 2 = no listing/validation either
 };
 
 template <bool REC16>
-__global__ void __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_num_sgpr(80))) k_fastq_pack(const fq_args a) {
+__global__ void __launch_bounds__(FQ_THREADS, 8) __attribute__((amdgpu_num_sgpr(80))) k_fastq_pack(const fq_args a) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[FQ_TILE + FQ_HALO_MAX];
     __shared__ __attribute__((aligned(8))) uint16_t masks[FQ_PIECES];      // newline mask of every 16-byte piece
     __shared__ uint32_t list[FQ_CAP], wtmp[17];
@@ -193,6 +243,7 @@ __global__ void __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_num_sgpr(80)
         rlo = tile == 0 ? 0u : seq_lines_before(ph, l0 + 1u < n_lines ? l0 + 1u : n_lines);
         rhi = seq_lines_before(ph, l1 + 1u < n_lines ? l1 + 1u : n_lines);
     }
+    if (a.dbg & 2u) return;
     for (uint32_t rb = rlo; rb < rhi || rb == rlo; rb += FQ_CAP) {
         // list the owned sequence lines [rb, rb + FQ_CAP): forward = stage offset of the line start, reverse = of its '\n'
         uint64_t mm = mine;
@@ -221,47 +272,55 @@ __global__ void __launch_bounds__(FQ_THREADS) __attribute__((amdgpu_num_sgpr(80)
         if (!a.reverse && tile == 0 && t == 0 && ph == 1u && rb == 0 && staged) list[0] = HB;    // the part starts with a sequence line
         __syncthreads();
         const uint32_t nrec = rhi - rb < FQ_CAP ? rhi - rb : FQ_CAP;
-        if (t < nrec) {
-            const uint8_t *s; uint64_t len;
-            if (!a.reverse) {
-                const uint32_t st = list[t];
+        // four lanes per listed line (a tile of ordinary reads holds ~200: one sweep of the 1024 lanes)
+        for (uint32_t i0 = 0; i0 < nrec && !(a.dbg & 1u); i0 += FQ_THREADS / 4u) {
+            const uint32_t i = i0 + (t >> 2), sub = t & 3u;
+            const bool have = i < nrec;
+            uint32_t so = 0, len = 0; uint64_t go = 0; bool in_lds = true;
+            if (have && !a.reverse) {
+                const uint32_t st = list[i];
                 const uint32_t lim = st + cap < staged ? st + cap : staged;
                 const uint32_t q = find_nl_fwd(m64, st, lim);
-                s = stage + st;
-                if (q < lim || (lim == staged && r0 + staged == a.n)) {      // the line ends at q (a newline, or the end of the part)
+                so = st;
+                if (q < lim || (lim == staged && r0 + staged == a.n)) {
                     len = q - st;
                     if (len && stage[q - 1] == 0x0D) len--;
                 } else if (lim - st == cap) {
-                    len = cap;                                               // at least cap bytes: every window is in bounds
+                    len = cap;
                 } else {
-                    // the halo is too short for this offset: walk the line in global memory
                     const uint64_t g0 = r0 + st;
                     uint64_t g = g0;
                     while (g < a.n && g - g0 < cap && a.text[g] != 0x0A) g++;
-                    len = g - g0;
+                    len = (uint32_t)(g - g0);
                     if (len && len < cap && a.text[g - 1] == 0x0D) len--;
-                    s = a.text + g0;
+                    go = g0; in_lds = false;
                 }
-            } else {
-                uint32_t e = list[t];                                        // the '\n' ending the sequence line
+            } else if (have) {
+                uint32_t e = list[i];
                 if (e && stage[e - 1] == 0x0D) e--;
                 const uint32_t lo = e > cap ? e - cap : 0u;
                 const uint32_t p = find_nl_bwd(m64, lo, e);
-                if (p != 0xFFFFFFFFu) { s = stage + p + 1u; len = e - (p + 1u); }
-                else if (e - lo == cap) { s = stage + lo; len = cap; }      // only the last cap bytes are ever addressed
-                else if (r0 == 0) { s = stage; len = e; }                    // the line starts the part
+                if (p != 0xFFFFFFFFu) { so = p + 1u; len = e - (p + 1u); }
+                else if (e - lo == cap) { so = lo; len = cap; }
+                else if (r0 == 0) { so = 0; len = e; }
                 else {
                     const uint64_t ge = r0 + e;
                     uint64_t g = ge;
                     while (g > 0 && ge - g < cap && a.text[g - 1] != 0x0A) g--;
-                    s = a.text + g; len = ge - g;
+                    go = g; len = (uint32_t)(ge - g); in_lds = false;
                 }
             }
-            uint64_t spn, sts;
-            sgc_pack_one(s, len, a.L, a.reverse, a.o, a.recursion, spn, sts);
-            const uint64_t r = (uint64_t)rb + t;
-            if (REC16) { a.recs[2 * r] = spn; a.recs[2 * r + 1] = sts; }
-            else a.recs[r] = spn | (sts << (2 * (a.L + 2)));
+            uint64_t spn, sts, spn2, sts2;
+            pack_quad(stage + so, len, have && in_lds, sub, a.L, a.reverse, a.o, a.recursion, spn, sts);
+            if (__builtin_amdgcn_ballot_w64(have && !in_lds)) {
+                pack_quad(a.text + go, len, have && !in_lds, sub, a.L, a.reverse, a.o, a.recursion, spn2, sts2);
+                if (!in_lds) { spn = spn2; sts = sts2; }
+            }
+            if (have && sub == 0) {
+                const uint64_t r = (uint64_t)rb + i;
+                if (REC16) { a.recs[2 * r] = spn; a.recs[2 * r + 1] = sts; }
+                else a.recs[r] = spn | (sts << (2 * (a.L + 2)));
+            }
         }
         if (rhi - rb <= FQ_CAP) break;
         __syncthreads();                                 // list[] is rewritten by the next round
@@ -284,9 +343,10 @@ void sgc_launch_fastq_count(hipStream_t st, const uint8_t *text, uint64_t n, uin
 
 void sgc_launch_fastq_pack(hipStream_t st, const uint8_t *text, uint64_t n, const uint32_t *tile_scratch, uint64_t first_line,
                            uint32_t expect_nl, uint32_t n_lines, uint32_t L, bool rec16, int reverse, uint32_t o, int recursion, uint64_t *recs,
-                           unsigned long long *err) {
+                           unsigned long long *err, uint32_t dbg) {
     if (n == 0) return;
     fq_args a;
+    a.dbg = dbg;
     a.text = text; a.n = n; a.tile_base = tile_scratch; a.first_line = first_line; a.recs = recs; a.err = err;
     a.tiles = sgc_fastq_tiles(n); a.expect_nl = expect_nl; a.n_lines = n_lines; a.L = L; a.o = o;
     const uint64_t want = ((uint64_t)o + L + 2u + 63u) & ~63ull;

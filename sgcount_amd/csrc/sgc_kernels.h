@@ -94,6 +94,6 @@ uint64_t sgc_fastq_records(uint64_t first_line, uint64_t n_lines);
 void sgc_launch_fastq_count(hipStream_t st, const uint8_t *text, uint64_t n, uint32_t *tile_scratch);
 void sgc_launch_fastq_pack(hipStream_t st, const uint8_t *text, uint64_t n, const uint32_t *tile_scratch, uint64_t first_line,
                            uint32_t expect_nl, uint32_t n_lines, uint32_t L, bool rec16, int reverse, uint32_t o, int recursion,
-                           uint64_t *recs, unsigned long long *err);
+                           uint64_t *recs, unsigned long long *err, uint32_t dbg);
 void sgc_launch_pack_reads_lds(hipStream_t st, const uint8_t *seqs, const uint64_t *offsets, uint64_t n, uint32_t L,
                                bool rec16, int reverse, uint32_t o, int recursion, uint64_t *recs);

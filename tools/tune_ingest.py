@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--reads", type=int, default=20_000_000)
     ap.add_argument("--guides", type=int, default=100_000)
     ap.add_argument("--chunk", type=int, default=10_000_000)
+    ap.add_argument("--dbg", type=int, default=0, help="timing-only ablation flags of k_fastq_pack (<< 24 into the ctx dbg word)")
     args = ap.parse_args()
     import torch
     from sgcount_amd import _ffi, synth
@@ -27,6 +28,9 @@ def main():
     smp = C.c_void_p()
     _ffi.check(dl.lib.sgc_sample_begin(dl.ctx, C.byref(smp), 0, 30, 1))
     dl.timing(True)
+    if args.dbg:
+        os.environ["SGC_ALLOW_DBG"] = "1"
+        dl.set_option("dbg", args.dbg << 24)
     for what in ("reads", "fastq"):
         tot_bytes, tot_ms, wall_ms = 0, 0.0, 0.0
         for first in range(0, args.reads, args.chunk):
@@ -52,7 +56,7 @@ def main():
                     e1.record()
                     torch.cuda.synchronize()
                     t = dl.timing(reset=True)
-                assert n.value == m
+                assert n.value == m or args.dbg
                 tot_bytes += fq.numel(); tot_ms += t.pack_ms; wall_ms += e0.elapsed_time(e1)
                 del fq
         print("%-6s -> records: %.2f GB in %.2f ms = %.2f TB/s, %.1f G reads/s" % (
