@@ -41,7 +41,8 @@ struct sgc_ctx {
     // library
     bool has_lib = false, one_mm = false, rec16 = false;
     uint32_t n = 0, L = 0;
-    uint64_t *d_lib_slots = nullptr, *d_perm_slots = nullptr;
+    uint64_t *d_lib_slots = nullptr, *d_perm_slots = nullptr, *d_lib_cuckoo = nullptr;
+    bool use_cuckoo = true;            // k_count_slices probes the two-choice image of the slices (no chain loop)
     uint32_t *d_lib_vals = nullptr, *d_perm_vals = nullptr;
     sgc_table_view v_lib{}, v_perm{};
     uint64_t *d_bloom_lib = nullptr, *d_bloom_perm = nullptr;
@@ -193,7 +194,7 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
                 uint64_t *buf0 = (uint64_t *)c->d_cbuf, *buf1 = (uint64_t *)((char *)c->d_cbuf + cg.runs_a_bytes);
                 void *zeroed = (char *)c->d_desc + g.desc_tail_off;
                 const sgc_runs ra = sgc_core_runs_a(cg, c->v_core[0], c->L, buf0, zeroed, c->d_csmall);
-                { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg, &ra); }
+                { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg, &ra, c->use_cuckoo ? c->d_lib_cuckoo : nullptr); }
                 // timing: miss_ms = core pass A (+ its epilogue), hist_ms = core pass B
                 { timed t(c, T_MISS, true); sgc_launch_core(c->stream, 0, c->L, c->v_lib, c->v_perm, c->v_core[0], c->v_core[1], c->d_amb, cg, buf0, buf1, pool,
                                                             zeroed, c->d_csmall, s->d_c32, s->d_matched, c->dbg); }
@@ -205,7 +206,7 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
                 if (done < n) { sgc_launch_fold(c->stream, s->d_c32, s->d_c64, c->n); s->since_fold = 0; }
                 continue;
             }
-            { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg, nullptr); }
+            { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg, nullptr, c->use_cuckoo ? c->d_lib_cuckoo : nullptr); }
             rc = ensure(&c->d_gids, &c->gids_cap, g.gids_bytes);                // one slot per pool record: every read may miss
             if (rc) return rc;
             rc = ensure(&c->d_aux, &c->aux_cap, ((size_t)g.n_segs + 1) * 4);
@@ -301,6 +302,8 @@ int sgc_init(int device, sgc_ctx **out) {
 
 static void free_tables(sgc_ctx *c) {
     if (c->d_lib_slots) hipFree(c->d_lib_slots);
+    if (c->d_lib_cuckoo) hipFree(c->d_lib_cuckoo);
+    c->d_lib_cuckoo = nullptr;
     if (c->d_perm_slots) hipFree(c->d_perm_slots);
     if (c->d_lib_vals) hipFree(c->d_lib_vals);
     if (c->d_perm_vals) hipFree(c->d_perm_vals);
@@ -379,6 +382,7 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
         c->max_chunk = (uint64_t)value; return SGC_OK;
     }
     if (!strcmp(key, "align_slices")) { c->align_slices = value != 0; return SGC_OK; }       // takes effect at the next sgc_set_library
+    if (!strcmp(key, "cuckoo")) { c->use_cuckoo = value != 0; return SGC_OK; }
     if (!strcmp(key, "rest_filter")) { c->rest_filter = value != 0; return SGC_OK; }         // takes effect at the next sgc_set_library
     if (!strcmp(key, "host_build")) { c->host_build = value != 0; return SGC_OK; }          // takes effect at the next sgc_set_library
     if (!strcmp(key, "perm_bloom_bits")) {
@@ -434,6 +438,17 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
     if (rc != SGC_OK) { free_tables(c); return rc; }
     rc = upload_bloom(keys, SGC_LIB_BLOOM_LOG2_WORDS, &c->d_bloom_lib, &c->b_lib, c->stream);
     if (rc != SGC_OK) { free_tables(c); return rc; }
+    if (sgc_part_supported(c->v_lib, L > SGC_REC8_MAXL)) {
+        // the partitioned path probes a two-choice image of every slice (k_count_slices<CUCKOO>)
+        std::vector<uint64_t> ck;
+        if (sgc_build_slice_cuckoo(h_lib, ck)) {
+            hipError_t e = hipMalloc((void **)&c->d_lib_cuckoo, ck.size() * 8);
+            if (e == hipSuccess) e = hipMemcpyAsync(c->d_lib_cuckoo, ck.data(), ck.size() * 8, hipMemcpyHostToDevice, c->stream);
+            const hipError_t e2 = hipStreamSynchronize(c->stream);
+            if (e == hipSuccess) e = e2;
+            if (e != hipSuccess) { free_tables(c); return fail(e == hipErrorOutOfMemory ? SGC_E_OOM : SGC_E_HIP, std::string("sgc_set_library: ") + hipGetErrorString(e)); }
+        }
+    }
     c->v_perm = sgc_table_view{nullptr, nullptr, 0, h_lib.gid_bits, 0, 0};
     c->perm_entries = 0;
     if (enable_1mm) {

@@ -136,6 +136,16 @@ SGC_HD uint32_t sgc_home_bucket_ex(uint64_t key, uint32_t log2_slots, uint32_t l
     const uint32_t hc = sgc_core_hash((uint32_t)((key >> 2) & ((1ull << (2 * core_cl)) - 1ull)));
     return (sgc_core_part(hc, log2_slots - log2_slice) << (log2_slice - 1)) | (sgc_hash32(key) >> (33 - log2_slice));
 }
+// Two-choice image of a library slice for k_count_slices (sgc_part.hip): a key sits in its home bucket b1 (the bucket
+// inside the slice that sgc_home_bucket_ex gives) or in the alternate bucket b1 ^ d(key), d != 0 — both 2-slot buckets are
+// read at once and the probe has no loop at all (the open-addressed layout needs one for full buckets, and its
+// exec-mask bookkeeping is most of that kernel's scalar instruction stream).  lb = log2(buckets per slice).
+SGC_HD uint32_t sgc_cuckoo_alt(uint64_t key, uint32_t b1, uint32_t lb) {
+    if (lb == 0) return b1;
+    uint32_t d = ((uint32_t)(key >> 3) * 0xC2B2AE35u) >> (32 - lb);
+    d |= (uint32_t)(d == 0);
+    return b1 ^ d;
+}
 SGC_HD uint32_t sgc_core_home(uint32_t h, uint32_t log2_p) {
     return (h >> (32 - log2_p - SGC_CORE_LOG2_S)) & ((1u << SGC_CORE_LOG2_S) - 1u);
 }

@@ -212,13 +212,15 @@ __global__ void __launch_bounds__(K1_THREADS) k_partition(const uint64_t *__rest
 //                 // blocks per group: one group is processed while the next is in flight
 #define K2_SCAN 16u              // descriptors examined per lane per scan chunk
 #define K2_GLIST 64u             // generic blocks listed per epilogue window
-template <int LOG2_SLICE>
+// CUCKOO: the slice is staged from its two-choice image (`cuck`, sgc_format.h sgc_cuckoo_alt): both candidate buckets are
+// read at once and the probe has no loop.
+template <int LOG2_SLICE, bool CUCKOO>
 __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(80))) k_count_slices(uint64_t *__restrict__ pool, uint32_t *__restrict__ desc,
                                                              const uint32_t *__restrict__ wcnt, const uint32_t *__restrict__ wlist,
                                                              uint32_t k1_wgs, uint32_t blocks_per_wg, uint32_t G, uint32_t L,
                                                              sgc_table_view lib, uint32_t *__restrict__ counts,
                                                              unsigned long long *__restrict__ matched, uint32_t dbg,
-                                                             const sgc_runs ep) {
+                                                             const sgc_runs ep, const uint64_t *__restrict__ cuck) {
     constexpr uint32_t S = 1u << LOG2_SLICE;
     constexpr uint32_t RPT = PART_BLOCK / K2_THREADS;       // records per thread per block
     constexpr uint32_t Q = K2_U * RPT;                       // records per thread per group
@@ -231,7 +233,9 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     const uint32_t slice = lib.log2_slice < (uint32_t)LOG2_SLICE ? (1u << lib.log2_slice) : S;   // small libraries
     const uint32_t bmask = slice / 2 - 1u, gid_bits = lib.gid_bits;
     const uint64_t kmask = sgc_key_mask(L);
-    const ulonglong2 *gtab = reinterpret_cast<const ulonglong2 *>(lib.slots) + (uint64_t)p * (slice / 2);
+    const uint64_t *gslots = CUCKOO ? cuck : lib.slots;                // where the slice's slots (key << gid_bits | gid) live
+    const uint32_t lb = (lib.log2_slice < (uint32_t)LOG2_SLICE ? lib.log2_slice : (uint32_t)LOG2_SLICE) - 1u;   // log2 buckets per slice
+    const ulonglong2 *gtab = reinterpret_cast<const ulonglong2 *>(gslots) + (uint64_t)p * (slice / 2);
     for (uint32_t i = t; i < S / 2; i += K2_THREADS) {      // bare keys in LDS (a key is < 2^60, so SGC_EMPTY stays distinct)
         ulonglong2 v = i < slice / 2 ? gtab[i] : make_ulonglong2(SGC_EMPTY, SGC_EMPTY);
         if (v.x != SGC_EMPTY) v.x >>= gid_bits;
@@ -272,8 +276,8 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
 #pragma unroll
             for (uint32_t k = 0; k < RPT; k++) {
                 const uint32_t j = k * K2_THREADS + t;
-                // a block has room for PART_BLOCK records: lanes past its fill read (and later ignore) stale slots
-                cur[u * RPT + k] = pool[(uint64_t)(ce[u] == 0xFFFFFFFFu ? 0u : ce[u] >> 11) * PART_BLOCK + j];
+                // lanes past the block's fill have nothing to read (one open block per K1 workgroup and slice is part empty)
+                cur[u * RPT + k] = (ce[u] != 0xFFFFFFFFu && j <= (ce[u] & 2047u)) ? pool[(uint64_t)(ce[u] >> 11) * PART_BLOCK + j] : 0ull;
             }
         }
         for (uint32_t li = 0; li < nl; li += K2_U) {
@@ -293,7 +297,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
 #pragma unroll
                 for (uint32_t k = 0; k < RPT; k++) {
                     const uint32_t j = k * K2_THREADS + t;
-                    nxt[u * RPT + k] = pool[(uint64_t)(ne == 0xFFFFFFFFu ? 0u : ne >> 11) * PART_BLOCK + j];
+                    nxt[u * RPT + k] = (ne != 0xFFFFFFFFu && j <= (ne & 2047u)) ? pool[(uint64_t)(ne >> 11) * PART_BLOCK + j] : 0ull;
                 }
             }
             // Centered-exact probe (src/counter.rs:111) of the Q records against the slice in LDS.  The LDS copy
@@ -309,13 +313,23 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 const uint64_t key = (cur[q] >> 2) & kmask;
                 uint32_t b = (uint32_t)(cur[q] >> PART_TAG_SHIFT);           // left there by k_partition
                 ulonglong2 wv = tab[b];
-                bool hit = wv.x == key || wv.y == key;
-                bool cont = valid && !hit && wv.y != SGC_EMPTY;
-                while (cont) {
-                    b = (b + 1) & bmask;
-                    wv = tab[b];
+                bool hit;
+                if (CUCKOO) {
+                    // the key is in its home bucket or in the alternate one: read both, no chain
+                    const uint32_t b2 = sgc_cuckoo_alt(key, b, lb);
+                    const ulonglong2 w2 = tab[b2];
+                    const bool h1 = wv.x == key || wv.y == key, h2 = w2.x == key || w2.y == key;
+                    hit = h1 || h2;
+                    if (h2) { b = b2; wv = w2; }
+                } else {
                     hit = wv.x == key || wv.y == key;
-                    cont = !hit && wv.y != SGC_EMPTY;
+                    bool cont = valid && !hit && wv.y != SGC_EMPTY;
+                    while (cont) {
+                        b = (b + 1) & bmask;
+                        wv = tab[b];
+                        hit = wv.x == key || wv.y == key;
+                        cont = !hit && wv.y != SGC_EMPTY;
+                    }
                 }
                 // Predicated, not branched (every exec-mask change costs scalar instructions, and K2 is bound by
                 // its scalar unit): lanes with nothing to add hit a scratch word of their own.
@@ -351,7 +365,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     for (uint32_t i = t; i < slice; i += K2_THREADS) {
         const uint32_t c = cnt[i];
         if (c) {
-            atomicAdd(&counts[(uint32_t)(lib.slots[(uint64_t)p * slice + i] & ((1ull << gid_bits) - 1ull))], c);
+            atomicAdd(&counts[(uint32_t)(gslots[(uint64_t)p * slice + i] & ((1ull << gid_bits) - 1ull))], c);
             local += c;
         }
     }
@@ -709,12 +723,16 @@ uint32_t sgc_part_k2_grid(const sgc_part_geometry &g) { return g.partitions * k2
 
 void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_part_geometry &g,
                         uint64_t *pool, uint32_t *desc, uint32_t *counts, unsigned long long *matched, uint32_t dbg,
-                        const sgc_runs *runs) {
+                        const sgc_runs *runs, const uint64_t *cuckoo) {
     const uint32_t G = k2_shares(g);
     sgc_runs none{};
-    hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE>), dim3(g.partitions * G), dim3(K2_THREADS), 0, st, pool, desc,
-                       (const uint32_t *)((const char *)desc + g.wcnt_off), (const uint32_t *)((const char *)desc + g.wlist_off),
-                       g.k1_wgs, g.blocks_per_wg, G, L, lib, counts, matched, dbg, runs ? *runs : none);
+    const uint32_t *wcnt = (const uint32_t *)((const char *)desc + g.wcnt_off), *wlist = (const uint32_t *)((const char *)desc + g.wlist_off);
+    if (cuckoo)
+        hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE, true>), dim3(g.partitions * G), dim3(K2_THREADS), 0, st, pool, desc, wcnt, wlist,
+                           g.k1_wgs, g.blocks_per_wg, G, L, lib, counts, matched, dbg, runs ? *runs : none, cuckoo);
+    else
+        hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE, false>), dim3(g.partitions * G), dim3(K2_THREADS), 0, st, pool, desc, wcnt, wlist,
+                           g.k1_wgs, g.blocks_per_wg, G, L, lib, counts, matched, dbg, runs ? *runs : none, cuckoo);
 }
 
 void sgc_launch_part_k3(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm,

@@ -260,3 +260,38 @@ void sgc_build_rest_filter(const std::vector<uint64_t> &keys, uint32_t cs, uint3
             out[a * words + (idx >> 5)] |= 1u << (idx & 31u);
         }
 }
+
+bool sgc_build_slice_cuckoo(const sgc_host_table &lib, std::vector<uint64_t> &out) {
+    if (lib.gid_bits == 0 || lib.log2_slice < 1 || lib.log2_slice > lib.log2_slots) return false;
+    const uint32_t S = 1u << lib.log2_slice, NB = S / 2, lb = lib.log2_slice - 1;
+    const size_t n_slices = (size_t)1 << (lib.log2_slots - lib.log2_slice);
+    out.assign(lib.slots.size(), SGC_EMPTY);
+    uint64_t rng = 0x243F6A8885A308D3ull;
+    for (size_t s = 0; s < n_slices; s++) {
+        uint64_t *t = &out[s * S];
+        for (uint32_t i = 0; i < S; i++) {
+            uint64_t cur = lib.slots[s * S + i];
+            if (cur == SGC_EMPTY) continue;
+            uint64_t key = cur >> lib.gid_bits;
+            uint32_t b = sgc_home_bucket_ex(key, lib.log2_slots, lib.log2_slice, lib.core_cl) & (NB - 1);
+            bool placed = false;
+            for (int kick = 0; kick < 2000 && !placed; kick++) {
+                const uint32_t b2 = sgc_cuckoo_alt(key, b, lb);
+                const uint32_t cand[2] = {b, b2};
+                for (int c = 0; c < 2 && !placed; c++)
+                    for (int k = 0; k < 2 && !placed; k++)
+                        if (t[2 * cand[c] + k] == SGC_EMPTY) { t[2 * cand[c] + k] = cur; placed = true; }
+                if (placed) break;
+                // evict a random occupant of one of the two buckets and re-place it from its other bucket
+                rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+                const uint32_t vb = cand[(rng >> 33) & 1], vk = (uint32_t)(rng >> 34) & 1;
+                std::swap(cur, t[2 * vb + vk]);
+                key = cur >> lib.gid_bits;
+                b = sgc_cuckoo_alt(key, vb, lb);      // the evicted key's other bucket (the relation is symmetric)
+                if (lb == 0) return false;
+            }
+            if (!placed) return false;
+        }
+    }
+    return true;
+}

@@ -49,6 +49,10 @@ struct sgc_host_core {
 };
 bool sgc_build_core_index(const std::vector<uint64_t> &keys, uint32_t L, uint32_t cs, uint32_t cl, sgc_host_core &out);
 
+// Two-choice (cuckoo) image of every slice of a packed, sliced library table (sgc_format.h sgc_cuckoo_alt): same size and slot
+// format as lib.slots.  Returns false if some slice cannot be placed (the caller then keeps the open-addressed probe).
+bool sgc_build_slice_cuckoo(const sgc_host_table &lib, std::vector<uint64_t> &out);
+
 // Rest filter of a core (sgc_format.h sgc_core_view::filt): 3 x 2^log2_bits bits, as 32-bit words.
 uint32_t sgc_rest_filter_log2(uint32_t n_guides);
 void sgc_build_rest_filter(const std::vector<uint64_t> &keys, uint32_t cs, uint32_t cl, uint32_t log2_bits, std::vector<uint32_t> &out);
