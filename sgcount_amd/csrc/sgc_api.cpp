@@ -42,6 +42,7 @@ struct sgc_ctx {
     bool has_lib = false, one_mm = false, rec16 = false;
     uint32_t n = 0, L = 0;
     uint64_t *d_lib_slots = nullptr, *d_perm_slots = nullptr, *d_lib_cuckoo = nullptr;
+    bool tag_sub = true;               // K1 tags the pass-A partition inside the slice, K2 counts misses by it (no histogram sweep)
     bool use_cuckoo = true;            // k_count_slices probes the two-choice image of the slices (no chain loop)
     uint32_t *d_lib_vals = nullptr, *d_perm_vals = nullptr;
     sgc_table_view v_lib{}, v_perm{};
@@ -181,8 +182,14 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
             if (rc) return rc;
             uint64_t *pool = (uint64_t *)c->d_pool;
             uint32_t *desc = (uint32_t *)c->d_desc;
-            { timed t(c, T_PART); sgc_launch_part_k1(c->stream, p, chunk, c->L, c->v_lib, g, pool, desc); }
-            if (c->variant >= 4 && c->one_mm && c->has_core) {
+            // with core-hashed slices whose count divides core pass A's partitions by 1, 2 or 4, K1 tags every clean record with its
+            // partition inside the slice and K2 counts its misses by it on the fly
+            const bool core_path = c->variant >= 4 && c->one_mm && c->has_core;
+            const int sub = (int)c->v_core[0].log2_p - ((int)c->v_lib.log2_slots - (int)c->v_lib.log2_slice);
+            const bool tag_sub = core_path && c->tag_sub && c->v_lib.core_cl == c->v_core[0].cl && c->v_lib.log2_slice < c->v_lib.log2_slots &&
+                                 sub >= 0 && sub <= 2;
+            { timed t(c, T_PART); sgc_launch_part_k1(c->stream, p, chunk, c->L, c->v_lib, tag_sub ? (uint32_t)sub : 0u, g, pool, desc); }
+            if (core_path) {
                 // everything the slice probe does not settle (its misses + the generic partition) is resolved in LDS by the
                 // two core passes; k_count_slices itself lays those records out as pass A's runs
                 sgc_core_geometry cg;
@@ -193,7 +200,8 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
                 if (rc) return rc;
                 uint64_t *buf0 = (uint64_t *)c->d_cbuf, *buf1 = (uint64_t *)((char *)c->d_cbuf + cg.runs_a_bytes);
                 void *zeroed = (char *)c->d_desc + g.desc_tail_off;
-                const sgc_runs ra = sgc_core_runs_a(cg, c->v_core[0], c->L, buf0, zeroed, c->d_csmall);
+                sgc_runs ra = sgc_core_runs_a(cg, c->v_core[0], c->L, buf0, zeroed, c->d_csmall);
+                if (tag_sub) ra.sub_bits = (uint32_t)sub;
                 { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg, &ra, c->use_cuckoo ? c->d_lib_cuckoo : nullptr); }
                 // timing: miss_ms = core pass A (+ its epilogue), hist_ms = core pass B
                 { timed t(c, T_MISS, true); sgc_launch_core(c->stream, 0, c->L, c->v_lib, c->v_perm, c->v_core[0], c->v_core[1], c->d_amb, cg, buf0, buf1, pool,
@@ -382,6 +390,7 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
         c->max_chunk = (uint64_t)value; return SGC_OK;
     }
     if (!strcmp(key, "align_slices")) { c->align_slices = value != 0; return SGC_OK; }       // takes effect at the next sgc_set_library
+    if (!strcmp(key, "tag_sub")) { c->tag_sub = value != 0; return SGC_OK; }
     if (!strcmp(key, "cuckoo")) { c->use_cuckoo = value != 0; return SGC_OK; }
     if (!strcmp(key, "rest_filter")) { c->rest_filter = value != 0; return SGC_OK; }         // takes effect at the next sgc_set_library
     if (!strcmp(key, "host_build")) { c->host_build = value != 0; return SGC_OK; }          // takes effect at the next sgc_set_library

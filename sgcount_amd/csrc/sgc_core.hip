@@ -342,6 +342,7 @@ static sgc_runs make_runs(uint64_t *recs, void *mats, size_t mat_bytes, uint32_t
     const uint32_t K = L + 2;
     sgc_runs r;
     r.recs = recs; r.cnt = (uint32_t *)mats; r.off = (uint32_t *)((char *)mats + mat_bytes); r.tot = tot; r.cursor = cursor; r.W = W;
+    r.sub_bits = 0xFFu;
     r.cs2 = 2 * cv.cs; r.log2_p = cv.log2_p; r.sh = 2 * K; r.dead_all = SGC_STATE_DEAD * (1 + K + K * K);
     r.cmask = (1ull << (2 * cv.cl)) - 1ull;
     return r;

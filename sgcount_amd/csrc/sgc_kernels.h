@@ -45,7 +45,8 @@ struct sgc_part_geometry {
 };
 bool sgc_part_supported(const sgc_table_view &lib, bool rec16);
 void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_part_geometry *g);
-void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib,
+// sub_bits: with core-hashed slices, log2 (1..2) of core pass A's partitions per slice, tagged into the clean records; else 0
+void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib, uint32_t sub_bits,
                         const sgc_part_geometry &g, uint64_t *pool, uint32_t *desc);
 struct sgc_runs;       // sgc_runs.h
 // runs != NULL: the leftovers (misses, generic blocks) are laid out as the runs of core pass A by the kernel's epilogue

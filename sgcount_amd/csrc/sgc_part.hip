@@ -59,21 +59,30 @@ static_assert(PART_TILE % PART_BLOCK == 0 || PART_BLOCK % PART_TILE == 0, "tile/
 // the writer and for every reader.  The front of block b starts at record part_front(b) and wraps inside the block.
 __device__ __forceinline__ uint32_t part_front(uint32_t b) { return ((b * 2654435761u) >> 26) << 4; }      // 64 starts, 128-B aligned
 #define PART_TAG_SHIFT 53u
-#define PART_TAG_MASK ((1ull << PART_TAG_SHIFT) - 1ull)
+#define PART_SUB_SHIFT 51u        // below the bucket tag: which of the <= 4 partitions of core pass A inside the slice (sub_bits <= 2)
+#define PART_TAG_MASK ((1ull << PART_SUB_SHIFT) - 1ull)
 // With slices that follow the core hash (sgc_table_view::core_cl, sgc_home_bucket_ex) a slice's misses fall into the few
 // partitions of core pass A that refine it, so the epilogue of k_count_slices writes a handful of streams, not hundreds.
+// sub_bits (0..2, only with core-hashed slices): the next bits of the core hash below the slice — the partition of core
+// pass A inside the slice — ride along too, so that k_count_slices can count its misses by that partition as it goes.
 __device__ __forceinline__ uint32_t part_of(uint64_t &rec, uint64_t kmask, uint32_t sh, uint32_t log2_slots,
-                                            uint32_t log2_slice, uint32_t core_cl) {
+                                            uint32_t log2_slice, uint32_t core_cl, uint32_t sub_bits) {
     if ((rec >> sh) != 0) return 1u << (log2_slots - log2_slice);
-    const uint32_t hb = sgc_home_bucket_ex((rec >> 2) & kmask, log2_slots, log2_slice, core_cl);
-    rec |= (uint64_t)(hb & ((1u << (log2_slice - 1)) - 1u)) << PART_TAG_SHIFT;
+    const uint64_t key = (rec >> 2) & kmask;
+    const uint32_t hb = sgc_home_bucket_ex(key, log2_slots, log2_slice, core_cl);
+    uint64_t tag = (uint64_t)(hb & ((1u << (log2_slice - 1)) - 1u)) << PART_TAG_SHIFT;
+    if (sub_bits) {
+        const uint32_t hc = sgc_core_hash((uint32_t)((key >> 2) & ((1ull << (2 * core_cl)) - 1ull)));
+        tag |= (uint64_t)(sgc_core_part(hc, log2_slots - log2_slice + sub_bits) & ((1u << sub_bits) - 1u)) << PART_SUB_SHIFT;
+    }
+    rec |= tag;
     return hb >> (log2_slice - 1);
 }
 
 // ------------------------------------------------------------------------------------------------ K1
 __global__ void __launch_bounds__(K1_THREADS) k_partition(const uint64_t *__restrict__ recs, uint64_t n, uint64_t per_wg,
                                                    uint32_t blocks_per_wg, uint32_t L, uint32_t log2_slots,
-                                                   uint32_t log2_slice, uint32_t core_cl, uint64_t *__restrict__ pool,
+                                                   uint32_t log2_slice, uint32_t core_cl, uint32_t sub_bits, uint64_t *__restrict__ pool,
                                                    uint32_t *__restrict__ desc, uint32_t *__restrict__ tail,
                                                    uint32_t tail_words, uint32_t *__restrict__ wcnt,
                                                    uint32_t *__restrict__ wlist) {
@@ -116,7 +125,7 @@ __global__ void __launch_bounds__(K1_THREADS) k_partition(const uint64_t *__rest
         for (uint32_t k = 0; k < PART_TILE / K1_THREADS; k++) {
             const uint32_t j = k * K1_THREADS + t;
             if (j < m) {
-                const uint32_t p = part_of(rec[k], kmask, sh, log2_slots, log2_slice, core_cl);
+                const uint32_t p = part_of(rec[k], kmask, sh, log2_slots, log2_slice, core_cl, sub_bits);
                 pr[k] = (p << 16) | atomicAdd(&cnt[p], 1u);
             }
         }
@@ -230,6 +239,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     __shared__ uint32_t miss_cnt[2][K2_U], scratch[128], pre[K2_THREADS], wtmp[17];
     __shared__ uint32_t hn[RUN_MAXP], rcur[RUN_MAXP], rbase, preg[K2_THREADS];   // epilogue: leftovers by partition of core pass A
     const uint32_t t = threadIdx.x, p = blockIdx.x / G, g = blockIdx.x % G;
+    const bool count_sub = ep.recs != nullptr && ep.sub_bits != 0xFFu;      // wave-uniform
     const uint32_t slice = lib.log2_slice < (uint32_t)LOG2_SLICE ? (1u << lib.log2_slice) : S;   // small libraries
     const uint32_t bmask = slice / 2 - 1u, gid_bits = lib.gid_bits;
     const uint64_t kmask = sgc_key_mask(L);
@@ -335,6 +345,9 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 // its scalar unit): lanes with nothing to add hit a scratch word of their own.
                 const bool hv = valid && hit, mv = valid && !hit;
                 atomicAdd(hv ? &cnt[2 * b + (wv.x == key ? 0u : 1u)] : &scratch[t & 63u], 1u);
+                // with K1's sub-partition tag the misses are counted by pass A's partition right here, and the epilogue's
+                // histogram sweep does not have to read the fronts once more
+                if (count_sub) atomicAdd(mv ? &hn[(p << ep.sub_bits) | ((uint32_t)(cur[q] >> PART_SUB_SHIFT) & 3u)] : &scratch[t & 63u], 1u);
                 const uint32_t pos = atomicAdd(mv ? &miss_cnt[par][u] : &scratch[64u + (t & 63u)], 1u);
                 if (mv) pool[(uint64_t)(ce[u] >> 11) * PART_BLOCK + ((part_front(ce[u] >> 11) + pos) & (PART_BLOCK - 1u))] = cur[q] & PART_TAG_MASK;
             }
@@ -410,8 +423,8 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 __syncthreads();
             }
             if (dbg & (65536u << sweep)) continue;
-            // slice blocks: the compacted misses at the (staggered) fronts
-            for (uint32_t i0 = wave; i0 < nl; i0 += 8u * (K2_THREADS / 64u)) {
+            // slice blocks: the compacted misses at the (staggered) fronts (already counted by the probe loop if K1 tagged them)
+            for (uint32_t i0 = wave; i0 < nl && !(sweep == 0 && count_sub); i0 += 8u * (K2_THREADS / 64u)) {
                 uint32_t e[8], mx = 0;
 #pragma unroll
                 for (uint32_t k = 0; k < 8; k++) {
@@ -710,10 +723,10 @@ void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_
     g->block_records = PART_BLOCK;
 }
 
-void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib,
+void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib, uint32_t sub_bits,
                         const sgc_part_geometry &g, uint64_t *pool, uint32_t *desc) {
     hipLaunchKernelGGL(k_partition, dim3(g.k1_wgs), dim3(K1_THREADS), 0, st, recs, n, g.per_wg, g.blocks_per_wg, L,
-                       lib.log2_slots, lib.log2_slice, lib.core_cl, pool, desc, (uint32_t *)((char *)desc + g.desc_tail_off), SGC_DESC_TAIL / 4,
+                       lib.log2_slots, lib.log2_slice, lib.core_cl, sub_bits, pool, desc, (uint32_t *)((char *)desc + g.desc_tail_off), SGC_DESC_TAIL / 4,
                        (uint32_t *)((char *)desc + g.wcnt_off), (uint32_t *)((char *)desc + g.wlist_off));
 }
 

@@ -25,6 +25,8 @@ struct sgc_runs {
     uint32_t *tot;         // [P]: sum over w of cnt (zeroed before the producers start)
     uint32_t *cursor;      // bump allocator over recs (zeroed before the producers start)
     uint32_t W;            // number of producer workgroups (<= 1024): columns of the matrices
+    uint32_t sub_bits;     // k_count_slices: log2 of the consuming pass's partitions per library slice when k_partition tagged
+                           // them into the records (0..2), 0xFF = not tagged
     // partition function of the consuming pass: hash of the record's core bases, or RUN_DROP for a record whose
     // three windows are all dead (a read too short for the Centered window, src/counter.rs:158-166: it cannot match,
     // and all such records are identical, so they would pile up in one partition)
