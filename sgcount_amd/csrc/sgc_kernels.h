@@ -53,7 +53,9 @@ struct sgc_runs;       // sgc_runs.h
 uint32_t sgc_part_k2_grid(const sgc_part_geometry &g);
 void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_part_geometry &g,
                         uint64_t *pool, uint32_t *desc, uint32_t *counts, unsigned long long *matched, uint32_t dbg,
-                        const sgc_runs *runs, const uint64_t *cuckoo /* two-choice image of the slices, or NULL */);
+                        const sgc_runs *runs, const uint64_t *cuckoo /* two-choice image of the slices, or NULL */,
+                        uint64_t *mrun /* with runs: buffer for the dense miss runs (as many records as the pool), or NULL */,
+                        uint32_t *mcur /* its bump allocator, zeroed */);
 void sgc_launch_part_k3(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm,
                         const sgc_bloom_view &bloom_lib, const sgc_bloom_view &bloom_perm, const sgc_part_geometry &g,
                         const uint64_t *pool, const uint32_t *desc, uint32_t *seg_cnt, uint32_t *gids, uint32_t dbg);
