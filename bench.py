@@ -477,8 +477,8 @@ def main():
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                            "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                            "traffic_note": traffic_note,
-                           "kernel": ("count pipeline (k_partition + k_count_slices + core partition/resolve kernels)" if not exact
-                                      else "count pipeline (k_partition + k_count_slices + k_generic + k_resolve_miss + k_hist_segments)"),
+                           "kernel": ("count pipeline (k_partition + k_count_slices + k_core<A> + k_core<B>)" if not exact
+                                      else "count pipeline (k_partition + k_count_slices + k_core<exact>)"),
                            "algorithmic_bytes_per_read": bpr,
                            # the strict accounting: the shipped path reads no permute-table sector, a read is one 8-byte record
                            "needed_bytes_per_read": NEEDED_BYTES, "achieved_on_needed_bytes": needed,

@@ -71,8 +71,9 @@ typedef struct {
     uint64_t perm_slots;       /* slots of the single-mismatch (permute) table, 0 if exact */
     uint64_t perm_entries;     /* unambiguous children stored (src/permutes.rs map.len(), ACGT children only) */
     uint64_t table_bytes;      /* device bytes of the tables and indexes */
-    uint64_t core_partitions;  /* partitions of each core index of the in-LDS single-mismatch resolver;
-                                  0 = no core index (exact mode, or the guides do not spread): probing resolver */
+    uint64_t core_partitions;  /* partitions of each core index of the in-LDS resolver (also built for exact
+                                  mode, where one exact-only pass uses it); 0 = no core index (L outside 4..23, split-layout
+                                  table, or the guides do not spread): probing resolver */
 } sgc_lib_info;
 
 /* ---- context: device + library tables -------------------------------------------------------- */

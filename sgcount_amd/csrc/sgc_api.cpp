@@ -186,7 +186,7 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
             uint32_t *desc = (uint32_t *)c->d_desc;
             // with core-hashed slices whose count divides core pass A's partitions by 1, 2 or 4, K1 tags every clean record with its
             // partition inside the slice and K2 counts its misses by it on the fly
-            const bool core_path = c->variant >= 4 && c->one_mm && c->has_core;
+            const bool core_path = c->variant >= 4 && c->has_core;
             const int sub = (int)c->v_core[0].log2_p - ((int)c->v_lib.log2_slots - (int)c->v_lib.log2_slice);
             const bool tag_sub = core_path && c->tag_sub && c->v_lib.core_cl == c->v_core[0].cl && c->v_lib.log2_slice < c->v_lib.log2_slots &&
                                  sub >= 0 && sub <= 2;
@@ -214,10 +214,16 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
                 { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg, &ra,
                                                                  c->use_cuckoo ? c->d_lib_cuckoo : nullptr, mrun, mcur); }
                 // timing: miss_ms = core pass A (+ its epilogue), hist_ms = core pass B
+                if (!c->one_mm) {
+                    timed t(c, T_MISS, true);
+                    sgc_launch_core(c->stream, 2, c->L, c->v_lib, c->v_perm, c->v_core[0], c->v_core[1], c->d_amb, cg, buf0, buf1, pool,
+                                    zeroed, c->d_csmall, s->d_c32, s->d_matched, c->dbg);
+                } else {
                 { timed t(c, T_MISS, true); sgc_launch_core(c->stream, 0, c->L, c->v_lib, c->v_perm, c->v_core[0], c->v_core[1], c->d_amb, cg, buf0, buf1, pool,
                                                             zeroed, c->d_csmall, s->d_c32, s->d_matched, c->dbg); }
                 { timed t(c, T_HIST, true); sgc_launch_core(c->stream, 1, c->L, c->v_lib, c->v_perm, c->v_core[0], c->v_core[1], c->d_amb, cg, buf0, buf1, pool,
                                                             zeroed, c->d_csmall, s->d_c32, s->d_matched, c->dbg); }
+                }
                 HIP_TRY(hipGetLastError());
                 done += chunk;
                 s->since_fold += chunk;
@@ -452,7 +458,7 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
     std::vector<uint64_t> keys;
     sgc_host_table h_lib, h_perm;
     std::string err;
-    const uint32_t want_cl = (enable_1mm && c->align_slices && L >= 4 && L <= SGC_REC8_MAXL) ? (L - 2) / 2 : 0;
+    const uint32_t want_cl = (c->align_slices && L >= 4 && L <= SGC_REC8_MAXL) ? (L - 2) / 2 : 0;
     int rc = sgc_build_library_table(seqs, n, L, SGC_LDS_LOG2_SLICE, want_cl, keys, h_lib, err);
     if (rc != SGC_OK) return fail(rc, "sgc_set_library: " + err);
     rc = upload_table(h_lib, &c->d_lib_slots, &c->d_lib_vals, &c->v_lib, c->stream);
@@ -472,12 +478,13 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
     }
     c->v_perm = sgc_table_view{nullptr, nullptr, 0, h_lib.gid_bits, 0, 0};
     c->perm_entries = 0;
+    std::vector<uint64_t> amb;
+    bool device_build = false;
     if (enable_1mm) {
         const uint32_t bpk = c->perm_bloom_bits;   // Bloom bits per child, rounded up to a power-of-two word count: 6.0 M children -> 8 MiB
         const uint64_t n_children = (uint64_t)n * 3 * L;
         const uint32_t bloom_log2 = sgc_bloom_log2_words(n_children, bpk, 10, 24);
-        std::vector<uint64_t> amb;
-        const bool device_build = h_lib.gid_bits != 0 && !c->host_build;
+        device_build = h_lib.gid_bits != 0 && !c->host_build;
         if (device_build) {
             // children, their table, its filter and the ambiguity masks are built on the GPU (sgc_build.hip)
             const uint32_t pl2 = sgc_permute_log2_slots(n_children);
@@ -517,7 +524,10 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
             rc = upload_bloom(child_keys, bloom_log2, &c->d_bloom_perm, &c->b_perm, c->stream);
             if (rc != SGC_OK) { free_tables(c); return rc; }
         }
-        // core indexes (variant 4): span bases [2, L) cut in two; absent => the probing resolver stays in charge
+    }
+    {
+        // core indexes (variant 4): span bases [2, L) cut in two; absent => the probing resolver stays in charge.  Built for -x
+        // too: there one exact-only pass over core A takes the place of the probing resolver (k_core<EXACT>)
         if (L >= 4 && L <= SGC_REC8_MAXL && h_lib.gid_bits != 0) {
             const uint32_t ca = (L - 2) / 2;
             sgc_host_core hc[2];
@@ -525,7 +535,7 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
                 hipError_t e = hipSuccess;
                 std::vector<uint32_t> filt;
                 const uint32_t fl2 = sgc_rest_filter_log2(n);
-                if (c->rest_filter) sgc_build_rest_filter(keys, hc[0].cs, hc[0].cl, fl2, filt);
+                if (c->rest_filter && enable_1mm) sgc_build_rest_filter(keys, hc[0].cs, hc[0].cl, fl2, filt);
                 for (int k = 0; k < 2 && e == hipSuccess; k++) {
                     e = hipMalloc((void **)&c->d_core_ents[k], hc[k].ents.size() * 8);
                     if (e == hipSuccess) e = hipMalloc((void **)&c->d_core_gids[k], hc[k].gids.size() * 4);
@@ -540,7 +550,7 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
                     if (e == hipSuccess) e = hipMemcpyAsync(c->d_core_filt, filt.data(), filt.size() * 4, hipMemcpyHostToDevice, c->stream);
                     c->v_core[0].filt = c->d_core_filt; c->v_core[0].filt_log2 = fl2;
                 }
-                if (e == hipSuccess && !device_build) {
+                if (e == hipSuccess && enable_1mm && !device_build) {
                     e = hipMalloc((void **)&c->d_amb, amb.size() * 8);
                     if (e == hipSuccess) e = hipMemcpyAsync(c->d_amb, amb.data(), amb.size() * 8, hipMemcpyHostToDevice, c->stream);
                 }

@@ -71,7 +71,10 @@ __device__ __forceinline__ void starts_from_totals(const uint32_t *__restrict__ 
 // FINAL = false (pass A): records with an undecided higher level are written to fwd[] (one run per workgroup, from the
 // position of its first input record in the partition-ordered numbering — it forwards at most what it reads), counted
 // by pass B's partitions on the way, and laid out as pass B's runs by the epilogue.  FINAL = true (pass B): undecided = no.
-template <bool FINAL>
+// EXACT (with FINAL): the -x mode (src/count.rs:103-107: no Permuter).  Only the exact levels exist, and a guide that equals a
+// window agrees with it on BOTH cores, so ONE pass over core A settles everything k_count_slices left: Plus-exact and
+// Minus-exact (src/counter.rs:123-130).  A window with an 'N' cannot equal an ACGT guide: invisible.
+template <bool FINAL, bool EXACT>
 __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(80))) k_core(
     const sgc_runs in, sgc_core_view cv, const ulonglong2 *__restrict__ amb, uint32_t L, sgc_table_view lib, sgc_table_view perm,
     uint64_t *__restrict__ fwd, const sgc_runs out, uint32_t *__restrict__ counts, unsigned long long *__restrict__ matched,
@@ -174,9 +177,15 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 if (st0 == SGC_STATE_DEAD) vis &= ~1u;
                 if (st1 == SGC_STATE_DEAD) vis &= ~2u;
                 if (st2 == SGC_STATE_DEAD) vis &= ~4u;
-                if (st0 >= 2) { const uint32_t j = st0 - 2; if (j >= ll0 && j < ll0 + cl) { vis &= ~1u; unk |= 1u; } else nr0 = 1u << (2 * (j < ll0 ? j : j - cl)); }
-                if (st1 >= 2) { const uint32_t j = st1 - 2; if (j >= ll1 && j < ll1 + cl) { vis &= ~2u; unk |= 2u; } else nr1 = 1u << (2 * (j < ll1 ? j : j - cl)); }
-                if (st2 >= 2) { const uint32_t j = st2 - 2; if (j >= ll2 && j < ll2 + cl) { vis &= ~4u; unk |= 4u; } else nr2 = 1u << (2 * (j < ll2 ? j : j - cl)); }
+                if (EXACT) {
+                    if (st0 >= 2) vis &= ~1u;
+                    if (st1 >= 2) vis &= ~2u;
+                    if (st2 >= 2) vis &= ~4u;
+                } else {
+                    if (st0 >= 2) { const uint32_t j = st0 - 2; if (j >= ll0 && j < ll0 + cl) { vis &= ~1u; unk |= 1u; } else nr0 = 1u << (2 * (j < ll0 ? j : j - cl)); }
+                    if (st1 >= 2) { const uint32_t j = st1 - 2; if (j >= ll1 && j < ll1 + cl) { vis &= ~2u; unk |= 2u; } else nr1 = 1u << (2 * (j < ll1 ? j : j - cl)); }
+                    if (st2 >= 2) { const uint32_t j = st2 - 2; if (j >= ll2 && j < ll2 + cl) { vis &= ~4u; unk |= 4u; } else nr2 = 1u << (2 * (j < ll2 ? j : j - cl)); }
+                }
             }
             if (SGC_STAMPS && (dbg & 512)) { const unsigned long long x = __builtin_amdgcn_s_memtime(); ts_unp += x - tsa; tsa = x; }
             uint32_t ex0 = SGC_NONE, ex1 = SGC_NONE, ex2 = SGC_NONE;      // entry of the exact guide
@@ -196,7 +205,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                     const uint32_t dm = ((x | (x >> 1)) & 0x55555555u) & ~nr;
                     const uint32_t d = (uint32_t)__popc(dm) + (nr ? 1u : 0u);
                     if (d == 0) { if (a == 0) ex0 = i; else if (a == 1) ex1 = i; else ex2 = i; }
-                    else if (d == 1) {
+                    else if (!EXACT && d == 1) {
                         cc += 1u << (8 * a);
                         if (a == 0) { k0 = i; d0 = dm; } else if (a == 1) { k1 = i; d1 = dm; } else { k2 = i; d2 = dm; }
                     }
@@ -208,9 +217,10 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             // found nothing).  um: the 1mm level cannot be decided here (a clean visible window with no
             // candidate — the substitution may sit inside the core — or an 'N' inside the core).
             const uint32_t cC = (cc >> 8) & 255u, cP = (cc >> 16) & 255u, cM = cc & 255u;
-            uint32_t lm = (ex1 != SGC_NONE ? 1u : 0u) | (cC == 1 ? 2u : 0u) | (ex2 != SGC_NONE ? 4u : 0u) | (cP == 1 ? 8u : 0u) |
-                          (ex0 != SGC_NONE ? 16u : 0u) | (cM == 1 ? 32u : 0u);
-            const uint32_t um = ((((vis >> 1) & 1u) && cC == 0 && !nr1) || (unk & 2u) ? 2u : 0u) |
+            uint32_t lm = (ex1 != SGC_NONE ? 1u : 0u) | (!EXACT && cC == 1 ? 2u : 0u) | (ex2 != SGC_NONE ? 4u : 0u) | (!EXACT && cP == 1 ? 8u : 0u) |
+                          (ex0 != SGC_NONE ? 16u : 0u) | (!EXACT && cM == 1 ? 32u : 0u);
+            const uint32_t um = EXACT ? 0u :
+                                ((((vis >> 1) & 1u) && cC == 0 && !nr1) || (unk & 2u) ? 2u : 0u) |
                                 ((((vis >> 2) & 1u) && cP == 0 && !nr2) || (unk & 4u) ? 8u : 0u) |
                                 (((vis & 1u) && cM == 0 && !nr0) || (unk & 1u) ? 32u : 0u);
             uint32_t lvl = 6, res = SGC_NONE;
@@ -362,19 +372,22 @@ void sgc_launch_core(hipStream_t st, int pass, uint32_t L, const sgc_table_view 
     const ulonglong2 *am = reinterpret_cast<const ulonglong2 *>(amb);
     const sgc_runs ra = sgc_core_runs_a(g, ca, L, buf0, zeroed, small);
     const sgc_runs rb = make_runs(buf2, (char *)small + 2 * g.mat_a, g.mat_b, z + CP_MAXP, z + 2 * CP_MAXP + 1, KC_GRID, cb, L);
-    if (pass == 0)      // pass A: the runs k_count_slices left in buf0; forwards go to buf1 run by run, then to buf2 as pass B's runs
-        hipLaunchKernelGGL((k_core<false>), dim3(KC_GRID), dim3(KC_THREADS), 0, st, ra, ca, am, L, lib, perm, buf1, rb, counts, matched, dbg);
+    if (pass == 2)      // -x: the one exact-only pass over the runs k_count_slices left in buf0
+        hipLaunchKernelGGL((k_core<true, true>), dim3(KC_GRID), dim3(KC_THREADS), 0, st, ra, ca, am, L, lib, perm, (uint64_t *)nullptr, ra,
+                           counts, matched, dbg);
+    else if (pass == 0) // pass A: the runs k_count_slices left in buf0; forwards go to buf1 run by run, then to buf2 as pass B's runs
+        hipLaunchKernelGGL((k_core<false, false>), dim3(KC_GRID), dim3(KC_THREADS), 0, st, ra, ca, am, L, lib, perm, buf1, rb, counts, matched, dbg);
     else                // pass B: what pass A forwarded
-        hipLaunchKernelGGL((k_core<true>), dim3(KC_GRID), dim3(KC_THREADS), 0, st, rb, cb, am, L, lib, perm, (uint64_t *)nullptr, rb,
+        hipLaunchKernelGGL((k_core<true, false>), dim3(KC_GRID), dim3(KC_THREADS), 0, st, rb, cb, am, L, lib, perm, (uint64_t *)nullptr, rb,
                            counts, matched, dbg);
 }
 
 // diagnostic (sgc_set_option "print_occupancy"): resident workgroups per CU as the runtime computes them
 void sgc_core_print_occupancy() {
     int a = -1, b = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_core<false>, KC_THREADS, 0);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_core<true>, KC_THREADS, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_core<false, false>, KC_THREADS, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_core<true, false>, KC_THREADS, 0);
     hipFuncAttributes fa;
-    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_core<false>));
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_core<false, false>));
     fprintf(stderr, "occupancy (workgroups/CU): k_core<A> %d k_core<B> %d; k_core<A> lds %zu regs %d\n", a, b, fa.sharedSizeBytes, fa.numRegs);
 }

@@ -74,7 +74,7 @@ void sgc_core_plan(uint64_t n, const sgc_core_view &a, const sgc_core_view &b, u
 // buf0: runs_a_bytes (pass A's runs); buf1: fwd_bytes (pass A's forwarded runs); buf2: >= fwd_bytes, pass B's runs (the slice
 // pool may serve: it is dead by then); zeroed: zero_bytes of zeros (stream-ordered before k_count_slices); small: small_bytes
 sgc_runs sgc_core_runs_a(const sgc_core_geometry &g, const sgc_core_view &ca, uint32_t L, uint64_t *buf0, void *zeroed, void *small);
-// pass: 0 = core A (reads buf0, forwards through buf1 into buf2), 1 = core B (reads buf2)
+// pass: 0 = core A (reads buf0, forwards through buf1 into buf2), 1 = core B (reads buf2), 2 = the single exact-only pass of -x (reads buf0)
 void sgc_launch_core(hipStream_t st, int pass, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm,
                      const sgc_core_view &ca, const sgc_core_view &cb, const uint64_t *amb, const sgc_core_geometry &g,
                      uint64_t *buf0, uint64_t *buf1, uint64_t *buf2, void *zeroed, void *small, uint32_t *counts,
