@@ -81,7 +81,7 @@ struct sgc_ctx {
                                 // 3 partitioned + probing miss resolver, 4 partitioned + in-LDS core resolver
     int per_lane = 4;           // records per lane in the v2 lookup kernel
     uint32_t dbg = 0;           // timing-only ablation flags (results are wrong when non-zero)
-    uint32_t k1_wgs = 256;      // workgroups of the partition kernel: few, so that few half-empty blocks are left open
+    uint32_t k1_wgs = 512;      // workgroups of the partition kernel: two per CU (more leave more half-empty blocks open, fewer expose its phases)
     uint64_t max_chunk = 1ull << 27;   // records per internal pass (bounds the scratch buffers)
     bool rest_filter = true;           // core pass A settles "no parent inside the core" with the rest filter (sgc_format.h)
     bool align_slices = true;          // build the library table with slices that follow the core hash (next sgc_set_library)

@@ -80,7 +80,7 @@ __device__ __forceinline__ uint32_t part_of(uint64_t &rec, uint64_t kmask, uint3
 }
 
 // ------------------------------------------------------------------------------------------------ K1
-__global__ void __launch_bounds__(K1_THREADS) k_partition(const uint64_t *__restrict__ recs, uint64_t n, uint64_t per_wg,
+__global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__restrict__ recs, uint64_t n, uint64_t per_wg,
                                                    uint32_t blocks_per_wg, uint32_t L, uint32_t log2_slots,
                                                    uint32_t log2_slice, uint32_t core_cl, uint32_t sub_bits, uint64_t *__restrict__ pool,
                                                    uint32_t *__restrict__ desc, uint32_t *__restrict__ tail,
@@ -100,14 +100,8 @@ __global__ void __launch_bounds__(K1_THREADS) k_partition(const uint64_t *__rest
     if (t < PART_ARR) { blk[t] = 0xFFFFFFFFu; fill[t] = PART_BLOCK; nblk[t] = 0; }
     if (t == 0) next_free = 0;
     __syncthreads();
-    // the records of the NEXT tile are requested before the current one is processed: one workgroup per CU walks
-    // its tiles in lockstep phases, so without this the HBM latency of every tile's loads is fully exposed
-    uint64_t nxt[PART_TILE / K1_THREADS];
-#pragma unroll
-    for (uint32_t k = 0; k < PART_TILE / K1_THREADS; k++) {
-        const uint64_t j = lo + (uint64_t)k * K1_THREADS + t;
-        nxt[k] = j < hi ? __builtin_nontemporal_load(&recs[j]) : 0ull;
-    }
+    // two workgroups per CU (64 VGPRs each: __launch_bounds__(1024, 8)) — while one waits for its tile's records the other
+    // ranks, stages or writes; a register prefetch of the next tile instead (one workgroup per CU, 80 VGPRs) measured slower
     for (uint64_t base = lo; base < hi; base += PART_TILE) {
         const uint32_t m = (uint32_t)(hi - base < PART_TILE ? hi - base : PART_TILE);
         if (t < PART_ARR) cnt[t] = 0;
@@ -115,11 +109,9 @@ __global__ void __launch_bounds__(K1_THREADS) k_partition(const uint64_t *__rest
         uint64_t rec[PART_TILE / K1_THREADS];
         uint32_t pr[PART_TILE / K1_THREADS];     // partition << 16 | rank inside the tile
 #pragma unroll
-        for (uint32_t k = 0; k < PART_TILE / K1_THREADS; k++) rec[k] = nxt[k];
-#pragma unroll
         for (uint32_t k = 0; k < PART_TILE / K1_THREADS; k++) {
-            const uint64_t j = base + PART_TILE + (uint64_t)k * K1_THREADS + t;
-            nxt[k] = j < hi ? __builtin_nontemporal_load(&recs[j]) : 0ull;
+            const uint32_t j = k * K1_THREADS + t;
+            if (j < m) rec[k] = __builtin_nontemporal_load(&recs[base + j]);
         }
 #pragma unroll
         for (uint32_t k = 0; k < PART_TILE / K1_THREADS; k++) {
