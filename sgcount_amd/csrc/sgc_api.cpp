@@ -579,7 +579,7 @@ int sgc_library_info(sgc_ctx *c, sgc_lib_info *out) {
     out->perm_slots = c->one_mm ? 1ull << c->v_perm.log2_slots : 0;
     out->perm_entries = c->perm_entries;
     const uint64_t per = c->v_lib.gid_bits ? 8 : 12;
-    out->table_bytes = (out->lib_slots + out->perm_slots) * per;
+    out->table_bytes = (out->lib_slots + out->perm_slots) * per + (c->d_lib_cuckoo ? out->lib_slots * 8 : 0);
     if (c->has_core) {
         out->core_partitions = 1ull << c->v_core[0].log2_p;
         for (int k = 0; k < 2; k++)

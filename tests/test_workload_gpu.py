@@ -298,6 +298,31 @@ def test_full_size_other_configs(env, exact, mode, tmp_path):
     wl.close()
 
 
+def test_more_than_2_32_reads_on_one_guide(env):
+    """Counter::count tallies in usize (src/counter.rs:18); the device counts in u32 per guide and folds into u64 before any
+    counter could wrap: 45 pushes of 100M copies of ONE read put 4.5e9 > 2^32 on a single guide (and on one slice, one slot)."""
+    import ctypes as C
+    torch, S, synth, workload = env
+    ffi = S._ffi
+    lib_seqs, library = workload.synth_library(100_000, 20)
+    read = b"T" * 30 + lib_seqs[31337].tobytes() + b"G" * 40
+    rec = S.pack_reads_host([read], 20, S.Offset.Forward(30), True)
+    n, reps = 100_000_000, 45
+    big = torch.full((n,), int(rec.view(np.int64)[0]), dtype=torch.int64, device="cuda")
+    dl = library.device(True)
+    dl.set_stream(torch.cuda.current_stream().cuda_stream)
+    smp = C.c_void_p()
+    ffi.check(dl.lib.sgc_sample_begin(dl.ctx, C.byref(smp), 0, 30, 1))
+    for _ in range(reps):
+        ffi.check(dl.lib.sgc_sample_push_packed(smp, big.data_ptr(), n, ffi.MEM_DEVICE))
+    out = np.zeros(100_000, dtype=np.uint64)
+    t, m = C.c_uint64(), C.c_uint64()
+    ffi.check(dl.lib.sgc_sample_finish(smp, out.ctypes.data, C.byref(t), C.byref(m)))
+    dl.lib.sgc_sample_free(smp)
+    assert t.value == m.value == reps * n > 2 ** 32
+    assert int(out[31337]) == reps * n and int(out.sum()) == reps * n
+
+
 def test_extreme_skew(env):
     """Adversarial input: 40M reads of which 30M are ONE guide (one slice, one slot), 6M a single one-mismatch
     variant of another guide, 4M one junk read.  Exercises K1's multi-block spills, K2's list overflow/rescan
