@@ -36,7 +36,7 @@ extern "C" {
 #define SGC_OK 0
 #define SGC_E_ARG (-1)          /* bad argument */
 #define SGC_E_HIP (-2)          /* HIP runtime error / no device */
-#define SGC_E_UNSUPPORTED (-3)  /* library the device path cannot represent (non-ACGT bytes, L > 30) */
+#define SGC_E_UNSUPPORTED (-3)  /* guide length outside 1..65535; packed records asked for a length outside 1..30 */
 #define SGC_E_DUPLICATE (-4)    /* duplicate library sequence — src/library.rs:91-96 panics */
 #define SGC_E_STATE (-5)        /* call order (no library set, sample finished, ...) */
 #define SGC_E_OOM (-6)
@@ -65,7 +65,7 @@ typedef struct {
 typedef struct {
     uint32_t n_guides;
     uint32_t guide_len;
-    uint32_t record_bytes;     /* 8 or 16 */
+    uint32_t record_bytes;     /* 8 or 16; 0 = byte-string path (non-ACGT library or L > 30): no packed records */
     uint32_t one_mismatch;     /* 1 if the permute table is resident */
     uint64_t lib_slots;        /* open-addressed slots of the library table */
     uint64_t perm_slots;       /* slots of the single-mismatch (permute) table, 0 if exact */
@@ -94,9 +94,13 @@ void *sgc_get_stream(sgc_ctx *);
 /* Library::from_reader (src/library.rs:17-21,89-99) + Permuter::new (src/permutes.rs:47-75) unless
  * enable_1mm == 0 (the reference's -x/--exact, src/count.rs:103-107).  seqs = n rows of L ASCII bytes
  * in library-file order.  Builds the device tables once; they are read-only afterwards and shared by
- * every sample of the ctx.  SGC_E_DUPLICATE mirrors the duplicate-sequence panic; SGC_E_UNSUPPORTED
- * is returned for sequences with bytes outside ACGT or L > SGC_MAX_GUIDE_LEN (the caller must fail
- * loudly: there is no CPU fallback behind this ABI).  On any error the ctx holds no library afterwards. */
+ * every sample of the ctx.  SGC_E_DUPLICATE mirrors the duplicate-sequence panic.  A library with
+ * bytes outside ACGT ('N', lowercase, anything: upstream compares raw bytes, src/library.rs:89-99) or
+ * with L > SGC_MAX_GUIDE_LEN has no packed record format: it is served by the byte-string path
+ * (hashed tables verified byte for byte, same rules, slower; sgc_library_info reports record_bytes
+ * == 0) — such a ctx takes reads and FASTQ text (sgc_sample_push_reads / _push_fastq*), and
+ * sgc_sample_push_packed / sgc_pack_reads_device return SGC_E_STATE.  On any error the ctx holds no
+ * library afterwards. */
 int sgc_set_library(sgc_ctx *, const uint8_t *seqs, uint32_t n, uint32_t L, int enable_1mm);
 int sgc_library_info(sgc_ctx *, sgc_lib_info *out);
 
@@ -183,7 +187,8 @@ void sgc_free_pinned(void *p);
 
 /* Tuning knobs (all results-preserving): "variant" (count path variant 0..4; default 4), "max_chunk"
  * (records per internal pass), "k1_wgs" (workgroups of the partition kernel), "per_lane" (variant 2), "host_build" /
- * "perm_bloom_bits" (how the next sgc_set_library builds the single-mismatch table and its filter).  No environment
+ * "perm_bloom_bits" (how the next sgc_set_library builds the single-mismatch table and its filter), "force_bytes" (the next
+ * sgc_set_library uses the byte-string path even for a library the packed path could serve).  No environment
  * variable changes what the library computes or which kernels it runs.  "dbg" sets
  * timing-only ablation flags of the kernels — results are WRONG while it is non-zero, so it is refused unless
  * SGC_ALLOW_DBG=1 is in the environment (tools/tune.py sets it). */

@@ -22,8 +22,8 @@ HOST_SRCS = [os.path.join("host", f) for f in ("sgh.cpp", "sgh_cli.cpp", "sgh_ca
 HOST_HDRS = [os.path.join("host", "sgh.hpp"), os.path.join(INC, "sgcount_hip.h")]
 
 TARGETS = {
-    SO: (["sgc_api.cpp", "sgc_tables.cpp", "sgc_kernels.hip", "sgc_part.hip", "sgc_core.hip", "sgc_build.hip", "sgc_fastq.hip"],
-         ["sgc_format.h", "sgc_device.h", "sgc_kernels.h", "sgc_tables.h", os.path.join(INC, "sgcount_hip.h")]),
+    SO: (["sgc_api.cpp", "sgc_tables.cpp", "sgc_kernels.hip", "sgc_part.hip", "sgc_core.hip", "sgc_build.hip", "sgc_fastq.hip", "sgc_bytes.hip"],
+         ["sgc_format.h", "sgc_device.h", "sgc_kernels.h", "sgc_tables.h", "sgc_bytes.h", "sgc_runs.h", os.path.join(INC, "sgcount_hip.h")]),
     SYNTH_SO: (["sgc_synth.hip"], ["sgc_format.h", "sgc_synth.h", os.path.join(INC, "sgcount_synth.h")]),
 }
 

@@ -601,14 +601,18 @@ static SampleCounts count_sample(sgc_ctx *ctx, const std::string &path, const Of
     if (!parsed_on_device) {
     FastxReader reader(path);                                                         // count.rs:24
     const uint32_t L = (uint32_t)library.size;
-    const size_t words = sgc_record_bytes(L) / 8;
+    sgc_lib_info info;
+    sgc_check(sgc_library_info(ctx, &info), "sgc_library_info");
+    // a library of arbitrary bytes or longer than 30 has no packed record format: the device works on the read bytes
+    const bool device_pack = opt.device_pack || info.record_bytes == 0;
+    const size_t words = info.record_bytes / 8;
     std::vector<uint8_t> bytes;
     std::vector<uint64_t> offsets(1, 0), recs;
     bytes.reserve(opt.batch_reads * 160);
     auto flush = [&]() {
         const uint64_t n = offsets.size() - 1;
         if (!n) return;
-        if (opt.device_pack) {
+        if (device_pack) {
             sgc_check(sgc_sample_push_reads(smp, bytes.data(), offsets.data(), n, SGC_MEM_HOST), "sgc_sample_push_reads");
         } else {
             recs.resize(n * words);

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/sgcount_hip.h"
+#include "sgc_bytes.h"
 #include "sgc_format.h"
 #include "sgc_kernels.h"
 #include "sgc_runs.h"
@@ -57,6 +58,14 @@ struct sgc_ctx {
     uint16_t *d_core_starts[2] = {nullptr, nullptr};
     uint32_t *d_core_filt = nullptr;
     sgc_core_view v_core[2] = {};
+    // generic byte-string path (sgc_bytes.h): libraries the 2-bit records cannot represent
+    bool bytes_mode = false;
+    bool force_bytes = false;          // serve every library through the byte-string path (next sgc_set_library; tests)
+    uint8_t *d_bytes_seqs = nullptr;
+    uint64_t *d_bytes_tags[2] = {nullptr, nullptr};
+    uint32_t *d_bytes_vals[2] = {nullptr, nullptr};
+    uint32_t *d_bytes_pl = nullptr;
+    sgc_bytes_view v_bytes{};
     void *d_cbuf = nullptr; size_t cbuf_cap = 0;        // two record buffers of the core passes
     void *d_csmall = nullptr; size_t csmall_cap = 0;    // their histograms / partition starts / extents
     // scratch (grown on demand, stream-ordered reuse)
@@ -276,6 +285,22 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
     return SGC_OK;
 }
 
+// the byte-string path (sgc_bytes.hip): read i = text[starts[i], ends[i])
+static int count_bytes(sgc_sample *s, const uint8_t *d_text, const uint64_t *d_starts, const uint64_t *d_ends, uint64_t n) {
+    sgc_ctx *c = s->ctx;
+    uint64_t done = 0;
+    while (done < n) {
+        const uint64_t chunk = std::min<uint64_t>(n - done, 1ull << 30);
+        if (s->since_fold + chunk > 0xFFFFFFF0ull) { sgc_launch_fold(c->stream, s->d_c32, s->d_c64, c->n); s->since_fold = 0; }
+        { timed t(c, T_LOOKUP); sgc_launch_bytes_count(c->stream, c->v_bytes, d_text, d_starts + done, d_ends + done, chunk, s->reverse, s->offset,
+                                                       s->recursion, c->one_mm, s->d_c32, s->d_matched); }
+        HIP_TRY(hipGetLastError());
+        done += chunk; s->since_fold += chunk;
+    }
+    s->total += n;
+    return SGC_OK;
+}
+
 // ---- ABI -------------------------------------------------------------------------------------------
 
 extern "C" {
@@ -343,6 +368,14 @@ static void free_tables(sgc_ctx *c) {
     if (c->d_amb) hipFree(c->d_amb);
     if (c->d_core_filt) hipFree(c->d_core_filt);
     c->d_amb = nullptr; c->d_core_filt = nullptr; c->has_core = false;
+    if (c->d_bytes_seqs) hipFree(c->d_bytes_seqs);
+    if (c->d_bytes_pl) hipFree(c->d_bytes_pl);
+    for (int k = 0; k < 2; k++) {
+        if (c->d_bytes_tags[k]) hipFree(c->d_bytes_tags[k]);
+        if (c->d_bytes_vals[k]) hipFree(c->d_bytes_vals[k]);
+        c->d_bytes_tags[k] = nullptr; c->d_bytes_vals[k] = nullptr;
+    }
+    c->d_bytes_seqs = nullptr; c->d_bytes_pl = nullptr; c->bytes_mode = false; c->v_bytes = sgc_bytes_view{};
     c->b_lib = sgc_bloom_view{}; c->b_perm = sgc_bloom_view{};
     c->d_lib_slots = c->d_perm_slots = nullptr;
     c->d_lib_vals = c->d_perm_vals = nullptr;
@@ -407,6 +440,7 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
         c->max_chunk = (uint64_t)value; return SGC_OK;
     }
     if (!strcmp(key, "align_slices")) { c->align_slices = value != 0; return SGC_OK; }       // takes effect at the next sgc_set_library
+    if (!strcmp(key, "force_bytes")) { c->force_bytes = value != 0; return SGC_OK; }         // takes effect at the next sgc_set_library
     if (!strcmp(key, "dense")) { c->dense = value != 0; return SGC_OK; }
     if (!strcmp(key, "tag_sub")) { c->tag_sub = value != 0; return SGC_OK; }
     if (!strcmp(key, "cuckoo")) { c->use_cuckoo = value != 0; return SGC_OK; }
@@ -450,6 +484,39 @@ static int upload_table(const sgc_host_table &h, uint64_t **d_slots, uint32_t **
     return SGC_OK;
 }
 
+// Libraries with bytes outside ACGT or longer than SGC_MAX_GUIDE_LEN: hashed byte-string tables (sgc_bytes.h), built on the host
+static int set_library_bytes(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, bool one_mm) {
+    sgc_host_bytes hb;
+    std::string err;
+    const int rc = sgc_build_bytes_tables(seqs, n, L, one_mm, hb, err);
+    if (rc != SGC_OK) return fail(rc, "sgc_set_library: " + err);
+    hipError_t e = hipMalloc((void **)&c->d_bytes_seqs, (size_t)n * L);
+    auto up = [&](void **d, const void *h, size_t bytes) {
+        if (e == hipSuccess) e = hipMalloc(d, bytes);
+        if (e == hipSuccess) e = hipMemcpyAsync(*d, h, bytes, hipMemcpyHostToDevice, c->stream);
+    };
+    if (e == hipSuccess) e = hipMemcpyAsync(c->d_bytes_seqs, seqs, (size_t)n * L, hipMemcpyHostToDevice, c->stream);
+    up((void **)&c->d_bytes_tags[0], hb.lib_tag.data(), hb.lib_tag.size() * 8);
+    up((void **)&c->d_bytes_vals[0], hb.lib_val.data(), hb.lib_val.size() * 4);
+    if (one_mm) {
+        up((void **)&c->d_bytes_tags[1], hb.perm_tag.data(), hb.perm_tag.size() * 8);
+        up((void **)&c->d_bytes_vals[1], hb.perm_val.data(), hb.perm_val.size() * 4);
+        up((void **)&c->d_bytes_pl, hb.perm_pl.data(), hb.perm_pl.size() * 4);
+    }
+    const hipError_t e2 = hipStreamSynchronize(c->stream);          // the host vectors must outlive the copies
+    if (e == hipSuccess) e = e2;
+    if (e != hipSuccess) {
+        free_tables(c);
+        return fail(e == hipErrorOutOfMemory ? SGC_E_OOM : SGC_E_HIP, std::string("sgc_set_library: ") + hipGetErrorString(e));
+    }
+    c->v_bytes = sgc_bytes_view{c->d_bytes_seqs, c->d_bytes_tags[0], c->d_bytes_vals[0], c->d_bytes_tags[1], c->d_bytes_vals[1], c->d_bytes_pl,
+                                n, L, hb.lib_log2, hb.perm_log2};
+    c->perm_entries = hb.perm_entries;
+    c->bytes_mode = true;
+    c->n = n; c->L = L; c->one_mm = one_mm; c->rec16 = false; c->has_lib = true;
+    return SGC_OK;
+}
+
 int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int enable_1mm) {
     if (!c || !seqs) return fail(SGC_E_ARG, "sgc_set_library: NULL argument");
     HIP_TRY(hipSetDevice(c->device));
@@ -458,8 +525,10 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
     std::vector<uint64_t> keys;
     sgc_host_table h_lib, h_perm;
     std::string err;
+    if (c->force_bytes && L >= 1 && n >= 1) return set_library_bytes(c, seqs, n, L, enable_1mm != 0);
     const uint32_t want_cl = (c->align_slices && L >= 4 && L <= SGC_REC8_MAXL) ? (L - 2) / 2 : 0;
     int rc = sgc_build_library_table(seqs, n, L, SGC_LDS_LOG2_SLICE, want_cl, keys, h_lib, err);
+    if (rc == SGC_E_UNSUPPORTED && L >= 1 && n >= 1) return set_library_bytes(c, seqs, n, L, enable_1mm != 0);
     if (rc != SGC_OK) return fail(rc, "sgc_set_library: " + err);
     rc = upload_table(h_lib, &c->d_lib_slots, &c->d_lib_vals, &c->v_lib, c->stream);
     if (rc != SGC_OK) { free_tables(c); return rc; }
@@ -575,6 +644,14 @@ int sgc_library_info(sgc_ctx *c, sgc_lib_info *out) {
     memset(out, 0, sizeof(*out));
     out->n_guides = c->n; out->guide_len = c->L; out->record_bytes = c->rec16 ? 16 : 8;
     out->one_mismatch = c->one_mm;
+    if (c->bytes_mode) {
+        out->record_bytes = 0;
+        out->lib_slots = 1ull << c->v_bytes.lib_log2;
+        out->perm_slots = c->one_mm ? 1ull << c->v_bytes.perm_log2 : 0;
+        out->perm_entries = c->perm_entries;
+        out->table_bytes = (uint64_t)c->n * c->L + out->lib_slots * 12 + out->perm_slots * 16;
+        return SGC_OK;
+    }
     out->lib_slots = 1ull << c->v_lib.log2_slots;
     out->perm_slots = c->one_mm ? 1ull << c->v_perm.log2_slots : 0;
     out->perm_entries = c->perm_entries;
@@ -596,6 +673,18 @@ int sgc_lookup(sgc_ctx *c, const uint8_t *tokens, uint64_t n, int which, int32_t
     if (which < 0 || which > 2) return fail(SGC_E_ARG, "sgc_lookup: which must be 0, 1 or 2");
     if (n == 0) return SGC_OK;
     HIP_TRY(hipSetDevice(c->device));
+    if (c->bytes_mode) {
+        int rc = ensure(&c->d_stage, &c->stage_cap, n * c->L);
+        if (rc) return rc;
+        rc = ensure(&c->d_aux, &c->aux_cap, n * 4);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(c->d_stage, tokens, n * c->L, hipMemcpyHostToDevice, c->stream));
+        sgc_launch_bytes_lookup(c->stream, c->v_bytes, (const uint8_t *)c->d_stage, n, which, c->one_mm, (int32_t *)c->d_aux);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(gid_out, c->d_aux, n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return SGC_OK;
+    }
     std::vector<uint64_t> keys(n);
     for (uint64_t i = 0; i < n; i++)
         if (!sgc_pack_key(tokens + i * c->L, c->L, keys[i])) keys[i] = SGC_EMPTY;   // non-ACGT token: no match
@@ -632,6 +721,7 @@ int sgc_pack_reads_device(sgc_ctx *c, const uint8_t *d_seqs, const uint64_t *d_o
                           uint32_t offset, int position_recursion, void *d_records_out) {
     if (!c || !d_offsets || (!d_records_out && n)) return fail(SGC_E_ARG, "sgc_pack_reads_device: NULL argument");
     if (!c->has_lib) return fail(SGC_E_STATE, "sgc_pack_reads_device: no library set");
+    if (c->bytes_mode) return fail(SGC_E_STATE, "sgc_pack_reads_device: this library has no packed record format (sgc_library_info: record_bytes == 0)");
     if (n == 0) return SGC_OK;
     HIP_TRY(hipSetDevice(c->device));
     {
@@ -685,6 +775,9 @@ int sgc_sample_push_packed(sgc_sample *s, const void *records, uint64_t n, int w
     if (!s || (!records && n)) return fail(SGC_E_ARG, "sgc_sample_push_packed: NULL argument");
     if (n == 0) return SGC_OK;
     sgc_ctx *c = s->ctx;
+    if (c->bytes_mode)
+        return fail(SGC_E_STATE, "sgc_sample_push_packed: this library has no packed record format (sgc_library_info: record_bytes == 0); "
+                                 "push reads or FASTQ text");
     HIP_TRY(hipSetDevice(c->device));
     const size_t bytes = (size_t)n * (c->rec16 ? 16 : 8);
     const uint64_t *d = (const uint64_t *)records;
@@ -717,6 +810,7 @@ int sgc_sample_push_reads(sgc_sample *s, const uint8_t *seqs, const uint64_t *of
     } else if (where != SGC_MEM_DEVICE) {
         return fail(SGC_E_ARG, "sgc_sample_push_reads: where must be SGC_MEM_HOST or SGC_MEM_DEVICE");
     }
+    if (c->bytes_mode) return count_bytes(s, d_seqs, d_off, d_off + 1, n);
     void *p = c->d_recs; size_t cap = c->recs_cap;
     int rc = ensure(&p, &cap, (size_t)n * (c->rec16 ? 16 : 8));
     c->d_recs = (uint64_t *)p; c->recs_cap = cap;
@@ -779,9 +873,21 @@ static int push_fastq_part(sgc_sample *s, const uint8_t *text, uint64_t n_bytes,
     // in a well-formed stream, so the announced newline count decides (a truncated record is the caller's to report).
     const uint64_t n_records = sgc_fastq_records(first_line, lines);
     void *p = c->d_recs; size_t cap = c->recs_cap;
-    rc = ensure(&p, &cap, (size_t)(n_records ? n_records : 1) * (c->rec16 ? 16 : 8));
+    rc = ensure(&p, &cap, (size_t)(n_records ? n_records : 1) * ((c->rec16 || c->bytes_mode) ? 16 : 8));
     c->d_recs = (uint64_t *)p; c->recs_cap = cap;
     if (rc) return rc;
+    if (c->bytes_mode) {
+        // no packed records: the (start, end) of every sequence line, then the byte-string chain on the text itself
+        uint64_t *starts = c->d_recs, *ends = c->d_recs + n_records;
+        { timed t(c, T_PACK, true); sgc_launch_fastq_lines(c->stream, d_text, n_bytes, tile_scratch, first_line, (uint32_t)n_newlines, (uint32_t)lines,
+                                                           starts, ends, s->d_err); }
+        HIP_TRY(hipGetLastError());
+        s->fastq_pushed = true;
+        if (n_records_out) *n_records_out = n_records;
+        rc = count_bytes(s, d_text, starts, ends, n_records);
+        if (slot >= 0) { HIP_TRY(hipEventRecord(c->ev_use[slot], c->stream)); c->use_recorded[slot] = true; }
+        return rc;
+    }
     {
         timed t(c, T_PACK, true);
         sgc_launch_fastq_pack(c->stream, d_text, n_bytes, tile_scratch, first_line, (uint32_t)n_newlines, (uint32_t)lines, c->L, c->rec16,

@@ -100,3 +100,13 @@ void sgc_launch_fastq_pack(hipStream_t st, const uint8_t *text, uint64_t n, cons
                            uint64_t *recs, unsigned long long *err, uint32_t dbg);
 void sgc_launch_pack_reads_lds(hipStream_t st, const uint8_t *seqs, const uint64_t *offsets, uint64_t n, uint32_t L,
                                bool rec16, int reverse, uint32_t o, int recursion, uint64_t *recs);
+
+// ---- generic byte-string path (sgc_bytes.hip; sgc_bytes.h) ------------------------------------------
+struct sgc_bytes_view;
+// starts/ends: sgc_fastq_records(first_line, n_lines) entries each, byte offsets of every sequence line of the part
+void sgc_launch_fastq_lines(hipStream_t st, const uint8_t *text, uint64_t n, const uint32_t *tile_scratch, uint64_t first_line,
+                            uint32_t expect_nl, uint32_t n_lines, uint64_t *starts, uint64_t *ends, unsigned long long *err);
+void sgc_launch_bytes_count(hipStream_t st, const sgc_bytes_view &v, const uint8_t *text, const uint64_t *starts, const uint64_t *ends,
+                            uint64_t n_reads, int reverse, uint32_t o, int recursion, bool one_mm, uint32_t *counts,
+                            unsigned long long *matched);
+void sgc_launch_bytes_lookup(hipStream_t st, const sgc_bytes_view &v, const uint8_t *tokens, uint64_t n, int which, bool one_mm, int32_t *out);

@@ -1,10 +1,13 @@
 // sgc_tables.cpp — host-side construction of the library and single-mismatch tables.
 #include "sgc_tables.h"
 
+#include <string.h>
+
 #include <algorithm>
 #include <utility>
 
 #include "../../include/sgcount_hip.h"
+#include "sgc_bytes.h"
 
 bool sgc_pack_key(const uint8_t *seq, uint32_t L, uint64_t &key) {
     key = 0;
@@ -294,4 +297,97 @@ bool sgc_build_slice_cuckoo(const sgc_host_table &lib, std::vector<uint64_t> &ou
         }
     }
     return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// generic byte-string tables (sgc_bytes.h)
+// ---------------------------------------------------------------------------------------------------------------------
+static uint64_t bytes_hash(const uint8_t *p, uint32_t L) {
+    uint64_t h = sgc_bytes_hash_init();
+    for (uint32_t i = 0; i < L; i++) h = sgc_bytes_hash_step(h, p[i]);
+    return sgc_bytes_hash_fin(h);
+}
+// hash of `p` with p[j] replaced by b
+static uint64_t bytes_hash_sub(const uint8_t *p, uint32_t L, uint32_t j, uint8_t b) {
+    uint64_t h = sgc_bytes_hash_init();
+    for (uint32_t i = 0; i < L; i++) h = sgc_bytes_hash_step(h, i == j ? b : p[i]);
+    return sgc_bytes_hash_fin(h);
+}
+
+int sgc_build_bytes_tables(const uint8_t *seqs, uint32_t n, uint32_t L, bool one_mm, sgc_host_bytes &out, std::string &err) {
+    if (L == 0 || L > SGC_BYTES_MAXL) { err = "guide length " + std::to_string(L) + " outside 1.." + std::to_string(SGC_BYTES_MAXL); return SGC_E_UNSUPPORTED; }
+    if (n == 0) { err = "empty library"; return SGC_E_ARG; }
+    out.lib_log2 = std::max<uint32_t>(4, ceil_log2((uint64_t)n * 2 + 1));
+    out.lib_tag.assign((size_t)1 << out.lib_log2, SGC_BYTES_EMPTY);
+    out.lib_val.assign((size_t)1 << out.lib_log2, SGC_NONE);
+    const uint32_t lmask = (1u << out.lib_log2) - 1u;
+    auto lib_find = [&](uint64_t h, const uint8_t *w) -> uint32_t {          // Library::contains on bytes
+        for (uint32_t s = sgc_bytes_slot(h, out.lib_log2);; s = (s + 1) & lmask) {
+            if (out.lib_tag[s] == SGC_BYTES_EMPTY) return SGC_NONE;
+            if (out.lib_tag[s] == h && memcmp(seqs + (size_t)out.lib_val[s] * L, w, L) == 0) return out.lib_val[s];
+        }
+    };
+    for (uint32_t i = 0; i < n; i++) {
+        const uint8_t *w = seqs + (size_t)i * L;
+        const uint64_t h = bytes_hash(w, L);
+        if (lib_find(h, w) != SGC_NONE) {                                      // src/library.rs:91-96
+            err = "Unexpected duplicate sequence in library found: " + std::string((const char *)w, L);
+            return SGC_E_DUPLICATE;
+        }
+        uint32_t s = sgc_bytes_slot(h, out.lib_log2);
+        while (out.lib_tag[s] != SGC_BYTES_EMPTY) s = (s + 1) & lmask;
+        out.lib_tag[s] = h; out.lib_val[s] = i;
+    }
+    out.perm_entries = 0;
+    if (!one_mm) return SGC_OK;
+    // children: every guide, every position, every letter of the lexicon that differs (src/permutes.rs:3,78-117)
+    static const uint8_t LEX[5] = {'A', 'C', 'G', 'T', 'N'};
+    struct Kid { uint64_t h; uint32_t g, j; uint8_t b; };
+    std::vector<Kid> kids;
+    kids.reserve((size_t)n * L * 4);
+    for (uint32_t g = 0; g < n; g++) {
+        const uint8_t *w = seqs + (size_t)g * L;
+        for (uint32_t j = 0; j < L; j++)
+            for (uint8_t b : LEX)
+                if (b != w[j]) kids.push_back(Kid{bytes_hash_sub(w, L, j, b), g, j, b});
+    }
+    std::sort(kids.begin(), kids.end(), [](const Kid &a, const Kid &b) { return a.h < b.h; });
+    auto same_child = [&](const Kid &a, const Kid &b) {                       // do two (guide, position, letter) triples spell one string?
+        const uint8_t *x = seqs + (size_t)a.g * L, *y = seqs + (size_t)b.g * L;
+        for (uint32_t i = 0; i < L; i++) {
+            const uint8_t cx = i == a.j ? a.b : x[i], cy = i == b.j ? b.b : y[i];
+            if (cx != cy) return false;
+        }
+        return true;
+    };
+    std::vector<size_t> keep;
+    std::vector<uint8_t> child(L);
+    for (size_t i = 0; i < kids.size();) {
+        size_t e = i;
+        while (e < kids.size() && kids[e].h == kids[i].h) e++;
+        // inside a run of equal hashes (almost always one string): a child survives iff no other triple spells the same string
+        for (size_t a = i; a < e; a++) {
+            bool unique = true;
+            for (size_t b = i; b < e && unique; b++)
+                if (b != a && same_child(kids[a], kids[b])) unique = false;
+            if (!unique) continue;
+            const uint8_t *w = seqs + (size_t)kids[a].g * L;
+            for (uint32_t k = 0; k < L; k++) child[k] = k == kids[a].j ? kids[a].b : w[k];
+            if (lib_find(kids[a].h, child.data()) != SGC_NONE) continue;       // a library member is a parent: nulled (permutes.rs:149-152)
+            keep.push_back(a);
+        }
+        i = e;
+    }
+    out.perm_log2 = std::max<uint32_t>(4, ceil_log2((uint64_t)keep.size() * 2 + 1));
+    out.perm_tag.assign((size_t)1 << out.perm_log2, SGC_BYTES_EMPTY);
+    out.perm_val.assign((size_t)1 << out.perm_log2, SGC_NONE);
+    out.perm_pl.assign((size_t)1 << out.perm_log2, 0);
+    const uint32_t pmask = (1u << out.perm_log2) - 1u;
+    for (size_t a : keep) {
+        uint32_t s = sgc_bytes_slot(kids[a].h, out.perm_log2);
+        while (out.perm_tag[s] != SGC_BYTES_EMPTY) s = (s + 1) & pmask;
+        out.perm_tag[s] = kids[a].h; out.perm_val[s] = kids[a].g; out.perm_pl[s] = kids[a].j | (uint32_t)kids[a].b << 24;
+    }
+    out.perm_entries = keep.size();
+    return SGC_OK;
 }

@@ -53,6 +53,17 @@ bool sgc_build_core_index(const std::vector<uint64_t> &keys, uint32_t L, uint32_
 // format as lib.slots.  Returns false if some slice cannot be placed (the caller then keeps the open-addressed probe).
 bool sgc_build_slice_cuckoo(const sgc_host_table &lib, std::vector<uint64_t> &out);
 
+// Generic byte-string tables (sgc_bytes.h) for a library of n sequences of L arbitrary bytes.  Returns 0 or SGC_E_DUPLICATE
+// (src/library.rs:91-96) with `err` set.  perm_* stay empty unless one_mm.
+struct sgc_host_bytes {
+    std::vector<uint64_t> lib_tag, perm_tag;
+    std::vector<uint32_t> lib_val, perm_val;
+    std::vector<uint32_t> perm_pl;
+    uint32_t lib_log2 = 0, perm_log2 = 0;
+    uint64_t perm_entries = 0;
+};
+int sgc_build_bytes_tables(const uint8_t *seqs, uint32_t n, uint32_t L, bool one_mm, sgc_host_bytes &out, std::string &err);
+
 // Rest filter of a core (sgc_format.h sgc_core_view::filt): 3 x 2^log2_bits bits, as 32-bit words.
 uint32_t sgc_rest_filter_log2(uint32_t n_guides);
 void sgc_build_rest_filter(const std::vector<uint64_t> &keys, uint32_t cs, uint32_t cl, uint32_t log2_bits, std::vector<uint32_t> &out);

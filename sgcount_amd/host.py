@@ -152,7 +152,7 @@ class Library:
     def device(self, one_mismatch: bool, device_index: int = 0, options=None):
         """The resident (library [+ permute]) tables for this library on one GPU.  options: sgc_set_option pairs applied
         before the tables are built (first call only)."""
-        key = (bool(one_mismatch), device_index)
+        key = (bool(one_mismatch), device_index, tuple(sorted((options or {}).items())))
         dl = self._devices.get(key)
         if dl is None:
             dl = DeviceLibrary(self, one_mismatch, device_index, options)
@@ -179,7 +179,8 @@ class DeviceLibrary:
             if e.code == _ffi.E_DUPLICATE:
                 raise RuntimeError(str(e)) from e
             raise
-        self.record_bytes = self.lib.sgc_record_bytes(library.size())
+        # 8 / 16, or 0: a library of arbitrary bytes or L > 30 has no packed record format (byte-string path: reads or FASTQ text only)
+        self.record_bytes = self.info().record_bytes
 
     def info(self):
         out = _ffi.LibInfo()
@@ -277,12 +278,16 @@ class Counter:
 
     @classmethod
     def new(cls, reader, library: Library, permuter, offset: Offset, size: int, position_recursion: bool,
-            pack: str = "host", batch: int = 1 << 20, device_index: int = 0):
+            pack: str = "host", batch: int = 1 << 20, device_index: int = 0, options=None):
         """Counter::new (src/counter.rs:36-66): consumes `reader`, returns the finished Counter.
-        pack = "host" (sgc_pack_reads_host, the north-star split) or "device" (pack kernel)."""
+        pack = "host" (sgc_pack_reads_host, the north-star split), "device" (pack kernel) or "fastq" (the reads as FASTQ
+        text through sgc_sample_push_fastq).  A library without a packed record format (non-ACGT bytes, L > 30) is
+        served from the read bytes whatever `pack` says — on the device either way."""
         if size != library.size():
             raise ValueError("size must equal library.size() (src/count.rs:31)")
-        dev = library.device(permuter is not None, device_index)
+        dev = library.device(permuter is not None, device_index, options)
+        if pack == "host" and dev.record_bytes == 0:
+            pack = "device"
         lib = dev.lib
         sample = C.c_void_p()
         _ffi.check(lib.sgc_sample_begin(dev.ctx, C.byref(sample), int(offset.is_reverse()), offset.index(),
@@ -299,8 +304,11 @@ class Counter:
                 elif pack == "device":
                     flat, offs = _flatten(chunk)
                     _ffi.check(lib.sgc_sample_push_reads(sample, flat, offs.ctypes.data, len(chunk), _ffi.MEM_HOST))
+                elif pack == "fastq":
+                    text = b"".join(b"@r\n%s\n+\n%s\n" % (r, b"I" * len(r)) for r in chunk)
+                    _ffi.check(lib.sgc_sample_push_fastq(sample, text, len(text), _ffi.MEM_HOST, None))
                 else:
-                    raise ValueError("pack must be 'host' or 'device'")
+                    raise ValueError("pack must be 'host', 'device' or 'fastq'")
                 _ffi.check(lib.sgc_sample_sync(sample))
                 chunk.clear()
 

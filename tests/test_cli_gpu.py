@@ -108,12 +108,40 @@ def test_error_paths(cli, tmp_path):
     open(gm, "wb").write(b"gene.0\tlib.0\n")
     code, _, err = run(cli, "-l", LIB, "-i", seq, "-a", "5", "-g", gm, "-q")
     assert code == 1 and "Missing sgRNA aliases in gene map: \"lib.1\"" in err        # count.rs:90-95 (first in file order)
-    n_lib = os.path.join(str(tmp_path), "n.fa")
-    open(n_lib, "wb").write(b">a\nACGTNCGTACGTACGTACGT\n")
-    code, _, err = run(cli, "-l", n_lib, "-i", seq, "-a", "5", "-q")
-    assert code == 1 and "outside ACGT" in err                                        # no CPU fallback: fails loudly
     code, out, _ = run(cli, "--help")
     assert code == 0 and "--library-path" in out and "--no-position-recursion" in out
+
+
+@pytest.mark.parametrize("pack", ["fastq", "device", "host"])
+def test_library_with_n_and_long_guides(cli, pack, tmp_path):
+    """Libraries the packed records cannot carry (an 'N' inside a guide; 34-base guides) go through the byte-string path
+    (sgc_bytes.h) whatever --pack says: same table as the oracle, which compares bytes like the reference does."""
+    import random
+    rng = random.Random(8)
+    for L, alpha in ((20, b"ACGTN"), (34, b"ACGT")):
+        guides = list({bytes(rng.choice(alpha) for _ in range(L)) for _ in range(300)})
+        if L == 20:
+            guides[0] = b"ACGTNCGTACGTACGTACGT"
+        lib_text = b"".join(b">g%d\n%s\n" % (i, g) for i, g in enumerate(guides))
+        reads = []
+        for i in range(5000):
+            g = bytearray(rng.choice(guides))
+            if rng.random() < 0.3:
+                g[rng.randrange(L)] = rng.choice(b"ACGTN")
+            pre = bytes(rng.choice(b"ACGT") for _ in range(6 + rng.choice([0, 0, 1, -1])))
+            r = pre + bytes(g) + b"GTTTTAGAGC"
+            reads.append(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)))
+        text = b"".join(reads)
+        lp, fq = os.path.join(str(tmp_path), "lib%d.fa" % L), os.path.join(str(tmp_path), "s%d.fastq" % L)
+        open(lp, "wb").write(lib_text)
+        open(fq, "wb").write(text)
+        rc, out, err = run(cli, "-l", lp, "-i", fq, "-a", "6", "-q", "--pack", pack)
+        assert rc == 0, err
+        assert out == oracle_table(lib_text, [text], ["s%d" % L], [(False, 6)], False, True)
+        assert out.count("\n") > 100
+        rc, out, err = run(cli, "-l", lp, "-i", fq, "-a", "6", "-q", "-x", "-p", "--pack", pack)      # exact, no recursion
+        assert rc == 0, err
+        assert out == oracle_table(lib_text, [text], ["s%d" % L], [(False, 6)], True, False)
 
 
 def test_python_count_wrapper(tmp_path, example_library_text, example_reads):

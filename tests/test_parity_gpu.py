@@ -101,12 +101,13 @@ def test_library_kats(S):
 
 
 def test_unsupported_library_fails_loudly(S):
+    """non-ACGT bytes and L > 30 are served by the byte-string path (tests/test_generic_gpu.py); what is left is refused"""
     ffi = S._ffi
     with pytest.raises(ffi.SgcError) as e:
-        _lib(S, b">a\nACNG\n").device(True)
+        _lib(S, b">a\n" + b"A" * 65536 + b"\n").device(False)
     assert e.value.code == ffi.E_UNSUPPORTED
     with pytest.raises(ffi.SgcError) as e:
-        _lib(S, b">a\n" + b"A" * 31 + b"\n").device(False)
+        S.pack_reads_host([b"ACGT"], 31, S.Offset.Forward(0), True)
     assert e.value.code == ffi.E_UNSUPPORTED
 
 
