@@ -44,6 +44,7 @@ struct sgc_ctx {
     uint32_t n = 0, L = 0;
     uint64_t *d_lib_slots = nullptr, *d_perm_slots = nullptr, *d_lib_cuckoo = nullptr;
     bool dense = true;                 // k_count_slices writes its misses as dense runs (no per-group barrier) instead of in place
+    bool direct = true;                // ... one run per partition of core pass A, consumed where it lies (needs dense + tag_sub)
     bool tag_sub = true;               // K1 tags the pass-A partition inside the slice, K2 counts misses by it (no histogram sweep)
     bool use_cuckoo = true;            // k_count_slices probes the two-choice image of the slices (no chain loop)
     uint32_t *d_lib_vals = nullptr, *d_perm_vals = nullptr;
@@ -83,7 +84,6 @@ struct sgc_ctx {
     uint64_t *d_recs = nullptr; size_t recs_cap = 0;    // records produced by the on-device packers
     void *d_gids = nullptr; size_t gids_cap = 0;        // per-read guide ids between the lookup and histogram kernels
     void *d_pool = nullptr; size_t pool_cap = 0;        // partitioned path: record blocks
-    void *d_mrun = nullptr; size_t mrun_cap = 0;        // partitioned path: dense miss runs of k_count_slices<DENSE>
     void *d_desc = nullptr; size_t desc_cap = 0;        // partitioned path: block descriptors
     // options
     int variant = 4;            // count path variant: 0 direct atomics, 1/2 gid array + LDS histogram,
@@ -203,25 +203,24 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
             if (core_path) {
                 // everything the slice probe does not settle (its misses + the generic partition) is resolved in LDS by the
                 // two core passes; k_count_slices itself lays those records out as pass A's runs
+                // direct runs: the misses go straight to per-partition runs inside one allocation with pass A's other input
+                // (runs region | miss runs | forward buffer); the run matrices get one more column per workgroup of a slice
+                const bool direct = c->dense && c->direct && tag_sub && sgc_part_k2_grid(g) + sgc_part_k2_shares(g) <= 1024u;
                 sgc_core_geometry cg;
-                sgc_core_plan(chunk, c->v_core[0], c->v_core[1], sgc_part_k2_grid(g), &cg);
-                rc = ensure(&c->d_cbuf, &c->cbuf_cap, (size_t)(cg.runs_a_bytes + cg.fwd_bytes));
+                sgc_core_plan(chunk, c->v_core[0], c->v_core[1], sgc_part_k2_grid(g) + (direct ? sgc_part_k2_shares(g) : 0u), &cg);
+                const size_t mrun_bytes = c->dense ? (size_t)g.pool_bytes << (direct ? (uint32_t)sub : 0u) : 0;
+                rc = ensure(&c->d_cbuf, &c->cbuf_cap, (size_t)(cg.runs_a_bytes + mrun_bytes + cg.fwd_bytes));
                 if (rc) return rc;
                 rc = ensure(&c->d_csmall, &c->csmall_cap, cg.small_bytes);
                 if (rc) return rc;
-                uint64_t *buf0 = (uint64_t *)c->d_cbuf, *buf1 = (uint64_t *)((char *)c->d_cbuf + cg.runs_a_bytes);
+                uint64_t *buf0 = (uint64_t *)c->d_cbuf, *mrun = c->dense ? (uint64_t *)((char *)c->d_cbuf + cg.runs_a_bytes) : nullptr;
+                uint64_t *buf1 = (uint64_t *)((char *)c->d_cbuf + cg.runs_a_bytes + mrun_bytes);
                 void *zeroed = (char *)c->d_desc + g.desc_tail_off;
                 sgc_runs ra = sgc_core_runs_a(cg, c->v_core[0], c->L, buf0, zeroed, c->d_csmall);
                 if (tag_sub) ra.sub_bits = (uint32_t)sub;
-                uint64_t *mrun = nullptr;
-                if (c->dense) {
-                    rc = ensure(&c->d_mrun, &c->mrun_cap, g.pool_bytes);
-                    if (rc) return rc;
-                    mrun = (uint64_t *)c->d_mrun;
-                }
                 uint32_t *mcur = (uint32_t *)zeroed + 2 * RUN_MAXP + 2;        // behind totals A | totals B | region cursors (zeroed by K1)
                 { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg, &ra,
-                                                                 c->use_cuckoo ? c->d_lib_cuckoo : nullptr, mrun, mcur); }
+                                                                 c->use_cuckoo ? c->d_lib_cuckoo : nullptr, mrun, mcur, direct); }
                 // timing: miss_ms = core pass A (+ its epilogue), hist_ms = core pass B
                 if (!c->one_mm) {
                     timed t(c, T_MISS, true);
@@ -239,7 +238,7 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
                 if (done < n) { sgc_launch_fold(c->stream, s->d_c32, s->d_c64, c->n); s->since_fold = 0; }
                 continue;
             }
-            { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg, nullptr, c->use_cuckoo ? c->d_lib_cuckoo : nullptr, nullptr, nullptr); }
+            { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg, nullptr, c->use_cuckoo ? c->d_lib_cuckoo : nullptr, nullptr, nullptr, false); }
             rc = ensure(&c->d_gids, &c->gids_cap, g.gids_bytes);                // one slot per pool record: every read may miss
             if (rc) return rc;
             rc = ensure(&c->d_aux, &c->aux_cap, ((size_t)g.n_segs + 1) * 4);
@@ -394,7 +393,6 @@ void sgc_free(sgc_ctx *c) {
     if (c->d_recs) hipFree(c->d_recs);
     if (c->d_gids) hipFree(c->d_gids);
     if (c->d_pool) hipFree(c->d_pool);
-    if (c->d_mrun) hipFree(c->d_mrun);
     if (c->d_desc) hipFree(c->d_desc);
     if (c->d_cbuf) hipFree(c->d_cbuf);
     if (c->d_csmall) hipFree(c->d_csmall);
@@ -442,6 +440,7 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
     if (!strcmp(key, "align_slices")) { c->align_slices = value != 0; return SGC_OK; }       // takes effect at the next sgc_set_library
     if (!strcmp(key, "force_bytes")) { c->force_bytes = value != 0; return SGC_OK; }         // takes effect at the next sgc_set_library
     if (!strcmp(key, "dense")) { c->dense = value != 0; return SGC_OK; }
+    if (!strcmp(key, "direct")) { c->direct = value != 0; return SGC_OK; }
     if (!strcmp(key, "tag_sub")) { c->tag_sub = value != 0; return SGC_OK; }
     if (!strcmp(key, "cuckoo")) { c->use_cuckoo = value != 0; return SGC_OK; }
     if (!strcmp(key, "rest_filter")) { c->rest_filter = value != 0; return SGC_OK; }         // takes effect at the next sgc_set_library

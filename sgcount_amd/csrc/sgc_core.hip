@@ -335,8 +335,8 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
 // the slice pool, which is dead once k_count_slices has handed its leftovers on —, small_bytes for the four
 // [P][W] matrices, zero_bytes of zeroed words (totals A | totals B | region cursors), which live in the zeroed tail of
 // the descriptor buffer.
-void sgc_core_plan(uint64_t n, const sgc_core_view &a, const sgc_core_view &b, uint32_t k2_grid, sgc_core_geometry *g) {
-    g->w = k2_grid;
+void sgc_core_plan(uint64_t n, const sgc_core_view &a, const sgc_core_view &b, uint32_t producers_a, sgc_core_geometry *g) {
+    g->w = producers_a;
     g->grid_a = g->grid_b = KC_GRID;
     g->runs_a_bytes = n * 8;
     g->fwd_bytes = n * 8;

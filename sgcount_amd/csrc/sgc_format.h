@@ -136,15 +136,24 @@ SGC_HD uint32_t sgc_home_bucket_ex(uint64_t key, uint32_t log2_slots, uint32_t l
     const uint32_t hc = sgc_core_hash((uint32_t)((key >> 2) & ((1ull << (2 * core_cl)) - 1ull)));
     return (sgc_core_part(hc, log2_slots - log2_slice) << (log2_slice - 1)) | (sgc_hash32(key) >> (33 - log2_slice));
 }
-// Two-choice image of a library slice for k_count_slices (sgc_part.hip): a key sits in its home bucket b1 (the bucket
-// inside the slice that sgc_home_bucket_ex gives) or in the alternate bucket b1 ^ d(key), d != 0 — both 2-slot buckets are
-// read at once and the probe has no loop at all (the open-addressed layout needs one for full buckets, and its
-// exec-mask bookkeeping is most of that kernel's scalar instruction stream).  lb = log2(buckets per slice).
-SGC_HD uint32_t sgc_cuckoo_alt(uint64_t key, uint32_t b1, uint32_t lb) {
-    if (lb == 0) return b1;
-    uint32_t d = ((uint32_t)(key >> 3) * 0xC2B2AE35u) >> (32 - lb);
+// Home SLOT of a key (log2_slots bits); its upper bits are sgc_home_bucket_ex.  The slot inside the slice is what
+// k_partition tags into a clean record and where the two-choice image below looks first.
+SGC_HD uint32_t sgc_home_slot_ex(uint64_t key, uint32_t log2_slots, uint32_t log2_slice, uint32_t core_cl) {
+    if (core_cl == 0 || log2_slice >= log2_slots) return (uint32_t)(sgc_hash(key) >> (64 - log2_slots));
+    const uint32_t hc = sgc_core_hash((uint32_t)((key >> 2) & ((1ull << (2 * core_cl)) - 1ull)));
+    return (sgc_core_part(hc, log2_slots - log2_slice) << log2_slice) | (sgc_hash32(key) >> (32 - log2_slice));
+}
+// Two-choice image of a library slice for k_count_slices (sgc_part.hip): ONE-slot buckets, a key sits in its home slot s1
+// (inside the slice) or in the alternate slot s1 ^ d(key), d != 0 — both are read at once (two 8-byte LDS reads: a random
+// 16-byte gather costs twice the bank-conflict cycles, and those were a quarter of that kernel's busy time) and the probe has
+// no loop at all (the open-addressed layout needs one for full buckets, and its exec-mask bookkeeping was most of that
+// kernel's scalar instruction stream).  The table is built at load <= 0.4, below the 0.5 threshold of two-choice cuckoo
+// placement with one-slot buckets.  ls = log2(slots per slice).
+SGC_HD uint32_t sgc_cuckoo_alt(uint64_t key, uint32_t s1, uint32_t ls) {
+    if (ls == 0) return s1;
+    uint32_t d = ((uint32_t)(key >> 3) * 0xC2B2AE35u) >> (32 - ls);
     d |= (uint32_t)(d == 0);
-    return b1 ^ d;
+    return s1 ^ d;
 }
 SGC_HD uint32_t sgc_core_home(uint32_t h, uint32_t log2_p) {
     return (h >> (32 - log2_p - SGC_CORE_LOG2_S)) & ((1u << SGC_CORE_LOG2_S) - 1u);

@@ -51,11 +51,15 @@ void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32
 struct sgc_runs;       // sgc_runs.h
 // runs != NULL: the leftovers (misses, generic blocks) are laid out as the runs of core pass A by the kernel's epilogue
 uint32_t sgc_part_k2_grid(const sgc_part_geometry &g);
+uint32_t sgc_part_k2_shares(const sgc_part_geometry &g);     // workgroups per slice
 void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_part_geometry &g,
                         uint64_t *pool, uint32_t *desc, uint32_t *counts, unsigned long long *matched, uint32_t dbg,
                         const sgc_runs *runs, const uint64_t *cuckoo /* two-choice image of the slices, or NULL */,
                         uint64_t *mrun /* with runs: buffer for the dense miss runs (as many records as the pool), or NULL */,
-                        uint32_t *mcur /* its bump allocator, zeroed */);
+                        uint32_t *mcur /* its bump allocator, zeroed */,
+                        bool direct_runs /* with mrun and tagged sub-partitions: the misses go straight to per-partition runs that are
+                                            pass A's input (mrun: pool records << runs->sub_bits, inside runs->recs' allocation; the run
+                                            matrices have shares + grid columns) */);
 void sgc_launch_part_k3(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm,
                         const sgc_bloom_view &bloom_lib, const sgc_bloom_view &bloom_perm, const sgc_part_geometry &g,
                         const uint64_t *pool, const uint32_t *desc, uint32_t *seg_cnt, uint32_t *gids, uint32_t dbg);
@@ -70,7 +74,7 @@ struct sgc_core_geometry {
     uint32_t w, grid_a, grid_b, pad_;       // w: producers of pass A's runs (the grid of k_count_slices)
     uint64_t runs_a_bytes, fwd_bytes, zero_bytes, small_bytes, mat_a, mat_b;
 };
-void sgc_core_plan(uint64_t n, const sgc_core_view &a, const sgc_core_view &b, uint32_t k2_grid, sgc_core_geometry *g);
+void sgc_core_plan(uint64_t n, const sgc_core_view &a, const sgc_core_view &b, uint32_t producers_a, sgc_core_geometry *g);
 // buf0: runs_a_bytes (pass A's runs); buf1: fwd_bytes (pass A's forwarded runs); buf2: >= fwd_bytes, pass B's runs (the slice
 // pool may serve: it is dead by then); zeroed: zero_bytes of zeros (stream-ordered before k_count_slices); small: small_bytes
 sgc_runs sgc_core_runs_a(const sgc_core_geometry &g, const sgc_core_view &ca, uint32_t L, uint64_t *buf0, void *zeroed, void *small);

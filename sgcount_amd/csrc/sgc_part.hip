@@ -50,16 +50,16 @@ static_assert(PART_TILE % PART_BLOCK == 0 || PART_BLOCK % PART_TILE == 0, "tile/
 // (an 'N', a dead window, a short read; ~2 % of reads) — the extra "generic" partition P_lib.  Those records
 // need the serial generic chain (sgc_assign); kept apart, they are resolved by full waves in k_generic
 // instead of stalling one or two lanes of almost every wave of the fast kernels.
-// A clean record (status 0) has nothing above its span bits, so the partition kernel leaves the key's bucket
-// inside its slice there (PART_TAG_SHIFT: 11 bits, 2 (L + 2) <= 50 for one-word records): k_count_slices then
+// A clean record (status 0) has nothing above its span bits, so the partition kernel leaves the key's home slot
+// inside its slice there (PART_TAG_SHIFT: 12 bits, 2 (L + 2) <= 50 for one-word records): k_count_slices then
 // probes without hashing the key a second time — the 64-bit multiply is a dozen quarter-rate vector instructions,
 // and that kernel is bound by vector issue.  Whoever hands a record on (the miss compaction) clears the tag.
 // The misses of a slice block are compacted in place, but not to the block's first slots: every block is 8 KiB-aligned,
 // so fronts that all start at offset 0 would land on the same few L2 / HBM channels (the first KiB of every 8 KiB) for
 // the writer and for every reader.  The front of block b starts at record part_front(b) and wraps inside the block.
 __device__ __forceinline__ uint32_t part_front(uint32_t b) { return ((b * 2654435761u) >> 26) << 4; }      // 64 starts, 128-B aligned
-#define PART_TAG_SHIFT 53u
-#define PART_SUB_SHIFT 51u        // below the bucket tag: which of the <= 4 partitions of core pass A inside the slice (sub_bits <= 2)
+#define PART_TAG_SHIFT 52u
+#define PART_SUB_SHIFT 50u        // below the bucket tag: which of the <= 4 partitions of core pass A inside the slice (sub_bits <= 2)
 #define PART_TAG_MASK ((1ull << PART_SUB_SHIFT) - 1ull)
 // With slices that follow the core hash (sgc_table_view::core_cl, sgc_home_bucket_ex) a slice's misses fall into the few
 // partitions of core pass A that refine it, so the epilogue of k_count_slices writes a handful of streams, not hundreds.
@@ -69,14 +69,14 @@ __device__ __forceinline__ uint32_t part_of(uint64_t &rec, uint64_t kmask, uint3
                                             uint32_t log2_slice, uint32_t core_cl, uint32_t sub_bits) {
     if ((rec >> sh) != 0) return 1u << (log2_slots - log2_slice);
     const uint64_t key = (rec >> 2) & kmask;
-    const uint32_t hb = sgc_home_bucket_ex(key, log2_slots, log2_slice, core_cl);
-    uint64_t tag = (uint64_t)(hb & ((1u << (log2_slice - 1)) - 1u)) << PART_TAG_SHIFT;
+    const uint32_t hs = sgc_home_slot_ex(key, log2_slots, log2_slice, core_cl);
+    uint64_t tag = (uint64_t)(hs & ((1u << log2_slice) - 1u)) << PART_TAG_SHIFT;
     if (sub_bits) {
         const uint32_t hc = sgc_core_hash((uint32_t)((key >> 2) & ((1ull << (2 * core_cl)) - 1ull)));
         tag |= (uint64_t)(sgc_core_part(hc, log2_slots - log2_slice + sub_bits) & ((1u << sub_bits) - 1u)) << PART_SUB_SHIFT;
     }
     rec |= tag;
-    return hb >> (log2_slice - 1);
+    return hs >> log2_slice;
 }
 
 // ------------------------------------------------------------------------------------------------ K1
@@ -213,14 +213,20 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
 //                 // blocks per group: one group is processed while the next is in flight
 #define K2_SCAN 16u              // descriptors examined per lane per scan chunk
 #define K2_GLIST 64u             // generic blocks listed per epilogue window
-// CUCKOO: the slice is staged from its two-choice image (`cuck`, sgc_format.h sgc_cuckoo_alt): both candidate buckets are
-// read at once and the probe has no loop.
+// CUCKOO: the slice is staged from its two-choice image (`cuck`, sgc_format.h sgc_cuckoo_alt): both candidate slots are
+// read at once (two 8-byte LDS reads) and the probe has no loop.
 // DENSE (only with ep.recs): the misses do not go back into their blocks but, densely, into a stretch of `mrun` the workgroup
 // takes at its start (as many records as its blocks hold: no miss can lack room).  Compacting in place needs a barrier per
 // group of blocks — a wave must not overwrite slots another wave has yet to load — and the descriptors rewritten; a dense run
 // needs neither (the position comes from ONE LDS atomic per wave step, after a ballot), and the epilogue reads it as one
 // contiguous range instead of a thousand-odd fronts.
-template <int LOG2_SLICE, bool CUCKOO, bool DENSE>
+// DIRECT (with DENSE, only when k_partition tagged the sub-partitions): the stretch is cut into one run per partition of core
+// pass A inside the slice (<= 4), every miss goes straight to the run of its partition (ONE LDS atomic per record: the position,
+// which is also the count), and those runs ARE pass A's input — published as producer column g (the workgroup's index inside
+// its slice) of the run matrices, nothing is read back or moved.  Only the workgroup's share of the generic blocks still goes
+// through the epilogue's histogram + placement, as producer column G + blockIdx.x.  mrun must be ep.recs + (an offset that
+// fits 32 bits); ep.W = G + gridDim.x.
+template <int LOG2_SLICE, bool CUCKOO, bool DENSE, bool DIRECT>
 __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(80))) k_count_slices(uint64_t *__restrict__ pool, uint32_t *__restrict__ desc,
                                                              const uint32_t *__restrict__ wcnt, const uint32_t *__restrict__ wlist,
                                                              uint32_t k1_wgs, uint32_t blocks_per_wg, uint32_t G, uint32_t L,
@@ -237,13 +243,15 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     __shared__ uint32_t miss_cnt[2][K2_U], scratch[128], pre[K2_THREADS], wtmp[17];
     __shared__ uint32_t hn[RUN_MAXP], rcur[RUN_MAXP], rbase, preg[K2_THREADS];   // epilogue: leftovers by partition of core pass A
     __shared__ uint32_t wmiss, mbase;                                              // DENSE: misses so far, start of the stretch in mrun
+    __shared__ uint32_t wmiss4[4];                                                 // DIRECT: misses so far, by sub-partition
     const uint32_t t = threadIdx.x, p = blockIdx.x / G, g = blockIdx.x % G;
     const bool count_sub = ep.recs != nullptr && ep.sub_bits != 0xFFu;      // wave-uniform
     const uint32_t slice = lib.log2_slice < (uint32_t)LOG2_SLICE ? (1u << lib.log2_slice) : S;   // small libraries
     const uint32_t bmask = slice / 2 - 1u, gid_bits = lib.gid_bits;
     const uint64_t kmask = sgc_key_mask(L);
     const uint64_t *gslots = CUCKOO ? cuck : lib.slots;                // where the slice's slots (key << gid_bits | gid) live
-    const uint32_t lb = (lib.log2_slice < (uint32_t)LOG2_SLICE ? lib.log2_slice : (uint32_t)LOG2_SLICE) - 1u;   // log2 buckets per slice
+    const uint32_t ls = lib.log2_slice < (uint32_t)LOG2_SLICE ? lib.log2_slice : (uint32_t)LOG2_SLICE;   // log2 slots per slice
+    const uint64_t *tab1 = reinterpret_cast<const uint64_t *>(tab);                                       // the same keys, slot by slot
     const ulonglong2 *gtab = reinterpret_cast<const ulonglong2 *>(gslots) + (uint64_t)p * (slice / 2);
     for (uint32_t i = t; i < S / 2; i += K2_THREADS) {      // bare keys in LDS (a key is < 2^60, so SGC_EMPTY stays distinct)
         ulonglong2 v = i < slice / 2 ? gtab[i] : make_ulonglong2(SGC_EMPTY, SGC_EMPTY);
@@ -266,8 +274,10 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     __syncthreads();
     const uint32_t s_lo = (uint32_t)((uint64_t)Bp * g / G), s_hi = (uint32_t)((uint64_t)Bp * (g + 1) / G);
     uint32_t run0 = 0;
+    const uint32_t stretch = (s_hi - s_lo) * PART_BLOCK;           // no run can lack room: as long as all blocks of the share
     if (DENSE) {
-        if (t == 0) { wmiss = 0; mbase = s_hi > s_lo ? atomicAdd(mcur, (s_hi - s_lo) * PART_BLOCK) : 0u; }
+        if (t < 4) wmiss4[t] = 0;
+        if (t == 0) { wmiss = 0; mbase = s_hi > s_lo ? atomicAdd(mcur, DIRECT ? stretch << ep.sub_bits : stretch) : 0u; }
         __syncthreads();
         run0 = mbase;
     }
@@ -326,17 +336,19 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 const uint32_t u = q / RPT, j = (q % RPT) * K2_THREADS + t;
                 const bool valid = ce[u] != 0xFFFFFFFFu && j <= (ce[u] & 2047u);
                 const uint64_t key = (cur[q] >> 2) & kmask;
-                uint32_t b = (uint32_t)(cur[q] >> PART_TAG_SHIFT);           // left there by k_partition
-                ulonglong2 wv = tab[b];
+                const uint32_t s1 = (uint32_t)(cur[q] >> PART_TAG_SHIFT);    // home slot inside the slice, left there by k_partition
+                uint32_t b = s1 >> 1, slot;
+                ulonglong2 wv;
                 bool hit;
                 if (CUCKOO) {
-                    // the key is in its home bucket or in the alternate one: read both, no chain
-                    const uint32_t b2 = sgc_cuckoo_alt(key, b, lb);
-                    const ulonglong2 w2 = tab[b2];
-                    const bool h1 = wv.x == key || wv.y == key, h2 = w2.x == key || w2.y == key;
-                    hit = h1 || h2;
-                    if (h2) { b = b2; wv = w2; }
+                    // the key is in its home slot or in the alternate one: read both, no chain
+                    const uint32_t s2 = sgc_cuckoo_alt(key, s1, ls);
+                    const uint64_t e1 = tab1[s1], e2 = tab1[s2];
+                    const bool h2 = e2 == key;
+                    hit = e1 == key || h2;
+                    slot = h2 ? s2 : s1;
                 } else {
+                    wv = tab[b];
                     hit = wv.x == key || wv.y == key;
                     bool cont = valid && !hit && wv.y != SGC_EMPTY;
                     while (cont) {
@@ -345,15 +357,20 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                         hit = wv.x == key || wv.y == key;
                         cont = !hit && wv.y != SGC_EMPTY;
                     }
+                    slot = 2 * b + (wv.x == key ? 0u : 1u);
                 }
                 // Predicated, not branched (every exec-mask change costs scalar instructions, and K2 is bound by
                 // its scalar unit): lanes with nothing to add hit a scratch word of their own.
                 const bool hv = valid && hit, mv = valid && !hit;
-                atomicAdd(hv ? &cnt[2 * b + (wv.x == key ? 0u : 1u)] : &scratch[t & 63u], 1u);
+                atomicAdd(hv ? &cnt[slot] : &scratch[t & 63u], 1u);
                 // with K1's sub-partition tag the misses are counted by pass A's partition right here, and the epilogue's
                 // histogram sweep does not have to read the fronts once more
-                if (count_sub) atomicAdd(mv ? &hn[(p << ep.sub_bits) | ((uint32_t)(cur[q] >> PART_SUB_SHIFT) & 3u)] : &scratch[t & 63u], 1u);
-                if (DENSE) {
+                if (count_sub && !DIRECT) atomicAdd(mv ? &hn[(p << ep.sub_bits) | ((uint32_t)(cur[q] >> PART_SUB_SHIFT) & 3u)] : &scratch[t & 63u], 1u);
+                if (DIRECT) {
+                    const uint32_t sub = (uint32_t)(cur[q] >> PART_SUB_SHIFT) & 3u;
+                    const uint32_t pos = atomicAdd(mv ? &wmiss4[sub] : &scratch[64u + (t & 63u)], 1u);
+                    if (mv) mrun[(uint64_t)run0 + sub * stretch + pos] = cur[q] & PART_TAG_MASK;
+                } else if (DENSE) {
                     // (a ballot + one atomic by the lowest missing lane measured 0.02 ms slower than this predicated add)
                     const uint32_t pos = atomicAdd(mv ? &wmiss : &scratch[64u + (t & 63u)], 1u);
                     if (mv) mrun[(uint64_t)run0 + pos] = cur[q] & PART_TAG_MASK;
@@ -387,7 +404,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     // flush the slot counters: one atomic per occupied slot
     uint64_t local = 0;
     for (uint32_t i = t; i < slice; i += K2_THREADS) {
-        const uint32_t c = cnt[i];
+        const uint32_t c = (dbg & 524288u) ? 0u : cnt[i];       // dbg 524288: timing-only, no flush
         if (c) {
             atomicAdd(&counts[(uint32_t)(gslots[(uint64_t)p * slice + i] & ((1ull << gid_bits) - 1ull))], c);
             local += c;
@@ -435,7 +452,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             }
             if (dbg & (65536u << sweep)) continue;
             // DENSE: the misses are one contiguous run (walked once, with the first window), eight loads in flight per lane
-            if (DENSE && ws == s_lo && !(sweep == 0 && count_sub)) {
+            if (DENSE && !DIRECT && ws == s_lo && !(sweep == 0 && count_sub)) {
                 const uint32_t M = wmiss;
                 for (uint32_t j0 = 0; j0 < M; j0 += 8u * K2_THREADS) {
                     uint64_t r[8];
@@ -492,7 +509,15 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             }
         }
         __syncthreads();
-        if (sweep == 0) run_reserve(ep, blockIdx.x, hn, rcur, wtmp, &rbase);
+        if (sweep == 0) run_reserve(ep, DIRECT ? G + blockIdx.x : blockIdx.x, hn, rcur, wtmp, &rbase);
+    }
+    if (DIRECT && t < (1u << ep.sub_bits)) {
+        // the direct runs: row (p << sub_bits | sub) of the run matrices belongs to this slice alone, so its G workgroups take
+        // columns 0 .. G - 1 of it (the generic shares follow from column G): no empty columns for the consumer to walk over
+        const uint32_t q = (p << ep.sub_bits) | t, c = wmiss4[t];
+        ep.cnt[(size_t)q * ep.W + g] = c;
+        ep.off[(size_t)q * ep.W + g] = (uint32_t)(mrun - ep.recs) + run0 + t * stretch;
+        if (c) atomicAdd(&ep.tot[q], c);
     }
 }
 
@@ -760,19 +785,21 @@ void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32
 // workgroups of k_count_slices: G per slice, two per CU in all — one resident generation
 static uint32_t k2_shares(const sgc_part_geometry &g) { return g.partitions >= 512 ? 1 : 512 / g.partitions; }
 uint32_t sgc_part_k2_grid(const sgc_part_geometry &g) { return g.partitions * k2_shares(g); }
+uint32_t sgc_part_k2_shares(const sgc_part_geometry &g) { return k2_shares(g); }
 
 void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_part_geometry &g,
                         uint64_t *pool, uint32_t *desc, uint32_t *counts, unsigned long long *matched, uint32_t dbg,
-                        const sgc_runs *runs, const uint64_t *cuckoo, uint64_t *mrun, uint32_t *mcur) {
+                        const sgc_runs *runs, const uint64_t *cuckoo, uint64_t *mrun, uint32_t *mcur, bool direct_runs) {
     const uint32_t G = k2_shares(g);
     sgc_runs none{};
     const uint32_t *wcnt = (const uint32_t *)((const char *)desc + g.wcnt_off), *wlist = (const uint32_t *)((const char *)desc + g.wlist_off);
     const bool dense = runs && mrun;
-#define K2_LAUNCH(CK, DN)                                                                                                              \
-    hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE, CK, DN>), dim3(g.partitions * G), dim3(K2_THREADS), 0, st, pool, desc, wcnt, wlist, \
+    const bool direct = dense && direct_runs && runs->sub_bits != 0xFFu;
+#define K2_LAUNCH(CK, DN, DR)                                                                                                          \
+    hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE, CK, DN, DR>), dim3(g.partitions * G), dim3(K2_THREADS), 0, st, pool, desc, wcnt, wlist, \
                        g.k1_wgs, g.blocks_per_wg, G, L, lib, counts, matched, dbg, runs ? *runs : none, cuckoo, mrun, mcur)
-    if (cuckoo) { if (dense) K2_LAUNCH(true, true); else K2_LAUNCH(true, false); }
-    else { if (dense) K2_LAUNCH(false, true); else K2_LAUNCH(false, false); }
+    if (cuckoo) { if (direct) K2_LAUNCH(true, true, true); else if (dense) K2_LAUNCH(true, true, false); else K2_LAUNCH(true, false, false); }
+    else { if (direct) K2_LAUNCH(false, true, true); else if (dense) K2_LAUNCH(false, true, false); else K2_LAUNCH(false, false, false); }
 #undef K2_LAUNCH
 }
 

@@ -266,7 +266,7 @@ void sgc_build_rest_filter(const std::vector<uint64_t> &keys, uint32_t cs, uint3
 
 bool sgc_build_slice_cuckoo(const sgc_host_table &lib, std::vector<uint64_t> &out) {
     if (lib.gid_bits == 0 || lib.log2_slice < 1 || lib.log2_slice > lib.log2_slots) return false;
-    const uint32_t S = 1u << lib.log2_slice, NB = S / 2, lb = lib.log2_slice - 1;
+    const uint32_t S = 1u << lib.log2_slice, ls = lib.log2_slice;
     const size_t n_slices = (size_t)1 << (lib.log2_slots - lib.log2_slice);
     out.assign(lib.slots.size(), SGC_EMPTY);
     uint64_t rng = 0x243F6A8885A308D3ull;
@@ -276,22 +276,18 @@ bool sgc_build_slice_cuckoo(const sgc_host_table &lib, std::vector<uint64_t> &ou
             uint64_t cur = lib.slots[s * S + i];
             if (cur == SGC_EMPTY) continue;
             uint64_t key = cur >> lib.gid_bits;
-            uint32_t b = sgc_home_bucket_ex(key, lib.log2_slots, lib.log2_slice, lib.core_cl) & (NB - 1);
+            uint32_t a = sgc_home_slot_ex(key, lib.log2_slots, lib.log2_slice, lib.core_cl) & (S - 1);
             bool placed = false;
-            for (int kick = 0; kick < 2000 && !placed; kick++) {
-                const uint32_t b2 = sgc_cuckoo_alt(key, b, lb);
-                const uint32_t cand[2] = {b, b2};
-                for (int c = 0; c < 2 && !placed; c++)
-                    for (int k = 0; k < 2 && !placed; k++)
-                        if (t[2 * cand[c] + k] == SGC_EMPTY) { t[2 * cand[c] + k] = cur; placed = true; }
-                if (placed) break;
-                // evict a random occupant of one of the two buckets and re-place it from its other bucket
+            for (int kick = 0; kick < 4000 && !placed; kick++) {
+                const uint32_t a2 = sgc_cuckoo_alt(key, a, ls);
+                if (t[a] == SGC_EMPTY) { t[a] = cur; placed = true; break; }
+                if (t[a2] == SGC_EMPTY) { t[a2] = cur; placed = true; break; }
+                // evict the occupant of one of the two slots and re-place it from its other slot
                 rng = rng * 6364136223846793005ull + 1442695040888963407ull;
-                const uint32_t vb = cand[(rng >> 33) & 1], vk = (uint32_t)(rng >> 34) & 1;
-                std::swap(cur, t[2 * vb + vk]);
+                const uint32_t v = (rng >> 33) & 1 ? a2 : a;
+                std::swap(cur, t[v]);
                 key = cur >> lib.gid_bits;
-                b = sgc_cuckoo_alt(key, vb, lb);      // the evicted key's other bucket (the relation is symmetric)
-                if (lb == 0) return false;
+                a = sgc_cuckoo_alt(key, v, ls);       // the evicted key's other slot (the relation is symmetric)
             }
             if (!placed) return false;
         }
