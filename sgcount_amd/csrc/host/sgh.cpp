@@ -3,6 +3,7 @@
 #include "sgh.hpp"
 
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -371,7 +372,7 @@ static double now_s() {
 }
 
 TextFeeder::TextFeeder(const std::string &path_, size_t slice_bytes, size_t ring, size_t threads, void *(*alloc)(size_t),
-                       void (*release)(void *))
+                       void (*release)(void *), size_t inflate_threads)
     : path(path_), free_fn(release) {
     fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) throw Error("No such file or directory (os error 2): " + path);
@@ -382,6 +383,18 @@ TextFeeder::TextFeeder(const std::string &path_, size_t slice_bytes, size_t ring
     file_size = (size_t)sb.st_size;
     is_gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
     if (is_gz) {
+        // BGZF?  (first member: FEXTRA with a 'B' 'C' subfield of length 2)
+        unsigned char hd[18];
+        if (pread(fd, hd, 18, 0) == 18 && hd[2] == 8 && (hd[3] & 4) && hd[10] + 256u * hd[11] >= 6 && hd[12] == 'B' && hd[13] == 'C' && hd[14] == 2 && hd[15] == 0 &&
+            file_size >= 28) {
+            void *m = mmap(nullptr, file_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) { map = (const uint8_t *)m; is_bgzf = true; madvise(m, file_size, MADV_SEQUENTIAL); }
+        }
+    }
+    if (is_bgzf) {
+        n_slices_known = (size_t)-1;                    // known when the member scan reaches the end of the file
+        threads = std::max(threads, inflate_threads);   // inflating is several times the work of copying
+    } else if (is_gz) {
         gz = gzdopen(dup(fd), "rb");
         if (!gz) { close(fd); throw Error("cannot open the gzip stream of " + path); }
         gzbuffer(gz, 1u << 20);
@@ -404,7 +417,13 @@ TextFeeder::TextFeeder(const std::string &path_, size_t slice_bytes, size_t ring
         if (!bufs[i]) { shutdown(); throw Error("cannot allocate pinned host buffers"); }
     }
     slots.resize(ring_n);
-    if (is_gz) {
+    plans.resize(ring_n);
+    if (is_bgzf) {
+        for (size_t t = 0; t < n_threads; t++) workers.emplace_back([this] { run_bgzf(); });
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this] { return (slots[0].ready && slots[0].index == 0) || failed; });
+        if (!failed) first_byte = slots[0].len ? bufs[0][HEAD] : 0;
+    } else if (is_gz) {
         // the first byte of the stream decides "FASTQ or not": inflate the first slice eagerly in the producer
         workers.emplace_back([this] { run_gz(); });
         // wait for slice 0 to learn the first byte
@@ -426,6 +445,7 @@ void TextFeeder::shutdown() {
     workers.clear();
     for (auto &b : bufs) if (b) { free_fn(b); b = nullptr; }
     if (gz) { gzclose(gz); gz = nullptr; }
+    if (map) { munmap((void *)map, file_size); map = nullptr; }
     if (fd >= 0) { close(fd); fd = -1; }
 }
 
@@ -478,6 +498,97 @@ void TextFeeder::run_plain() {
         if (!failed) { failed = true; error = e.what(); }
         cv.notify_all();
     }
+}
+
+// BGZF: the members from scan_off on whose inflated sizes (ISIZE trailers) fit one slice.  Called under the lock, for
+// k = 0, 1, 2, ... in order.
+void TextFeeder::plan_bgzf_slice(size_t k) {
+    std::vector<BlockRef> &pl = plans[k % ring_n];
+    pl.clear();
+    size_t out = 0;
+    while (scan_off < file_size) {
+        const uint8_t *h = map + scan_off;
+        if (file_size - scan_off < 28 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4))
+            throw Error("corrupt BGZF member header in " + path);
+        const size_t xlen = h[10] + 256u * h[11];
+        if (12 + xlen + 8 > file_size - scan_off) throw Error("corrupt BGZF member header in " + path);
+        size_t bsize = 0;
+        for (size_t x = 12; x + 4 <= 12 + xlen;) {                       // the extra subfields: SI1 SI2 SLEN data
+            const size_t slen = h[x + 2] + 256u * h[x + 3];
+            if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2 && x + 6 <= 12 + xlen) bsize = (size_t)(h[x + 4] + 256u * h[x + 5]) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || bsize > file_size - scan_off) throw Error("corrupt BGZF member (no usable BC subfield) in " + path);
+        const uint8_t *tr = h + bsize - 8;
+        const uint32_t crc = tr[0] | tr[1] << 8 | tr[2] << 16 | (uint32_t)tr[3] << 24;
+        const uint32_t isize = tr[4] | tr[5] << 8 | tr[6] << 16 | (uint32_t)tr[7] << 24;
+        if (isize > slice) throw Error("BGZF member larger than a slice in " + path);
+        if (out + isize > slice) break;
+        pl.push_back(BlockRef{scan_off + 12 + xlen, (uint32_t)(bsize - 12 - xlen - 8), (uint32_t)out, isize, crc});
+        out += isize;
+        scan_off += bsize;
+    }
+    Slot &sl = slots[k % ring_n];
+    sl.index = k; sl.ready = false; sl.pending = n_threads; sl.newlines = 0; sl.len = out; sl.eof = scan_off >= file_size;
+    if (sl.eof) n_slices_known = k + 1;
+    planned = k + 1;
+}
+
+void TextFeeder::run_bgzf() {
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, -15) != Z_OK) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!failed) { failed = true; error = "cannot initialise zlib"; }
+        cv.notify_all();
+        return;
+    }
+    try {
+        for (;;) {
+            size_t job, k;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                job = next_job++;
+                k = job / n_threads;
+                // slices are planned in order (the member scan is sequential) by whichever of their jobs gets here first
+                cv.wait(lk, [&] { return stop || failed || k >= n_slices_known || (k < released + ring_n && planned >= k); });
+                if (stop || failed || k >= n_slices_known) break;
+                if (planned == k) { plan_bgzf_slice(k); cv.notify_all(); }
+            }
+            const size_t j = job % n_threads;
+            const std::vector<BlockRef> &pl = plans[k % ring_n];
+            const size_t per = (pl.size() + n_threads - 1) / n_threads;
+            const size_t lo = std::min(pl.size(), j * per), hi = std::min(pl.size(), lo + per);
+            uint8_t *dst = bufs[k % ring_n] + HEAD;
+            const double t0 = now_s();
+            uint64_t nl = 0;
+            for (size_t b = lo; b < hi; b++) {
+                const BlockRef &r = pl[b];
+                if (r.out_len == 0) continue;                          // e.g. the empty end-of-file member
+                inflateReset(&zs);
+                zs.next_in = (Bytef *)(map + r.in_off); zs.avail_in = r.in_len;
+                zs.next_out = dst + r.out_off; zs.avail_out = r.out_len;
+                const int rc = inflate(&zs, Z_FINISH);
+                if (rc != Z_STREAM_END || zs.avail_out != 0 || (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst + r.out_off, r.out_len) != r.crc)
+                    throw Error("corrupt BGZF member in " + path);
+                nl += count_newlines(dst + r.out_off, r.out_len);
+            }
+            const double dt = now_s() - t0;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                Slot &sl = slots[k % ring_n];
+                sl.newlines += nl;
+                busy_s += dt;
+                if (--sl.pending == 0) sl.ready = true;
+            }
+            cv.notify_all();
+        }
+    } catch (const std::exception &e) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!failed) { failed = true; error = e.what(); }
+        cv.notify_all();
+    }
+    inflateEnd(&zs);
 }
 
 // gzip streams: one inflating producer (a deflate stream is sequential), slices filled in order
@@ -540,7 +651,8 @@ void TextFeeder::release_below(size_t k) {
 // Streams one FASTQ file through sgc_sample_push_fastq_part.  Returns false (nothing pushed) if the input is not
 // FASTQ (first byte not '@'): the caller then uses the record reader.
 static bool count_fastq_text(sgc_sample *smp, const std::string &path, const CountOptions &opt, SampleStats *st) {
-    TextFeeder feed(path, std::max<size_t>(opt.chunk_bytes, 1u << 16), 3, opt.io_threads, sgc_alloc_pinned, sgc_free_pinned);
+    TextFeeder feed(path, std::max<size_t>(opt.chunk_bytes, 1u << 16), 3, opt.io_threads, sgc_alloc_pinned, sgc_free_pinned,
+                    opt.inflate_threads);
     if (feed.first_byte != '@') return false;
     uint64_t first_line = 0;
     size_t carry = 0;                                  // bytes of an unfinished line, already sitting in front of the slice
@@ -585,7 +697,7 @@ static bool count_fastq_text(sgc_sample *smp, const std::string &path, const Cou
         st->text_bytes = feed.is_gz ? 0 : feed.file_size;
         st->reader_threads = feed.n_threads;
         st->read_busy_s = feed.busy_s; st->read_wait_s = feed.wait_s; st->push_s = t_push; st->upload_wait_s = t_upwait;
-        st->gz = feed.is_gz;
+        st->gz = feed.is_gz; st->bgzf = feed.is_bgzf;
     }
     return true;
 }
@@ -682,6 +794,7 @@ void count(const CountOptions &opt_in) {
     if (opt.io_threads == 0) {
         const size_t hw = std::max(1u, std::thread::hardware_concurrency());
         opt.io_threads = std::max<size_t>(1, std::min<size_t>(8, hw / n_workers));
+        opt.inflate_threads = std::max<size_t>(1, std::min<size_t>(16, hw / n_workers));      // BGZF members, inflated in parallel
     }
     std::string flat;
     flat.reserve(library.seqs.size() * library.size);
@@ -750,10 +863,10 @@ void count(const CountOptions &opt_in) {
                 t_lib - t_start, t_tables - t_lib, t_counted - t_tables, t_end - t_counted, t_end - t_start, n_dev, ctxs.size(), n_threads);
         for (size_t i = 0; i < n; i++) {
             const SampleStats &x = stats[i];
-            fprintf(f, "%s{\"device\": %d, \"reads\": %llu, \"text_bytes\": %llu, \"gz\": %s, \"text_path\": %s, \"reader_threads\": %zu, "
+            fprintf(f, "%s{\"device\": %d, \"reads\": %llu, \"text_bytes\": %llu, \"gz\": %s, \"bgzf\": %s, \"text_path\": %s, \"reader_threads\": %zu, "
                        "\"wall_s\": %.6f, \"read_busy_s\": %.6f, \"wait_for_text_s\": %.6f, \"push_s\": %.6f, \"wait_for_upload_s\": %.6f, "
                        "\"finish_s\": %.6f, \"h2d_ms\": %.3f, \"ingest_kernels_ms\": %.3f, \"count_kernels_ms\": %.3f}",
-                    i ? ", " : "", sample_dev[i], (unsigned long long)x.reads, (unsigned long long)x.text_bytes, x.gz ? "true" : "false",
+                    i ? ", " : "", sample_dev[i], (unsigned long long)x.reads, (unsigned long long)x.text_bytes, x.gz ? "true" : "false", x.bgzf ? "true" : "false",
                     x.text_path ? "true" : "false", x.reader_threads, x.wall_s, x.read_busy_s, x.read_wait_s, x.push_s,
                     x.upload_wait_s, x.finish_s, x.h2d_ms, x.ingest_ms, x.count_ms);
         }

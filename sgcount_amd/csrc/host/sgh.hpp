@@ -96,6 +96,7 @@ struct CountOptions {
     bool device_parse = true;            // FASTQ inputs: ship text, find record boundaries on the GPU
     size_t chunk_bytes = 64u << 20;      // bytes of text per slice (one upload) for device_parse
     size_t io_threads = 0;               // reader threads per sample for plain FASTQ (0 = min(8, cores / worker threads))
+    size_t inflate_threads = 0;          // inflating threads per BGZF sample (set with io_threads == 0: min(16, cores / worker threads))
     size_t batch_reads = 1u << 20;
     std::string stats_path;              // if set: per-stage timings of the run as JSON (bench.py's e2e block)
     size_t max_devices = 0;              // use at most this many of the visible GPUs (0 = all)
@@ -110,33 +111,43 @@ struct SampleStats {                    // where one sample's wall time went (ho
     double h2d_ms = 0, ingest_ms = 0, count_ms = 0;
     uint64_t text_bytes = 0, reads = 0;
     size_t reader_threads = 0;
-    bool gz = false, text_path = false;
+    bool gz = false, bgzf = false, text_path = false;
 };
 
 // Fills a small ring of (pinned) buffers with consecutive slices of a file's text and counts the newlines of every
 // slice on the way.  Plain files: `threads` readers pread() disjoint sub-ranges of a slice in parallel (page cache →
-// buffer is a memory copy, one core does ~5-10 GB/s of it).  gzip streams (by magic number): one inflating producer.
+// buffer is a memory copy, one core does ~5-10 GB/s of it).  gzip streams (by magic number): one inflating producer —
+// unless the file is BGZF (gzip members of <= 64 KiB that announce their own size in a 'BC' extra field: bgzip, htslib and
+// Illumina's converters write it): the members are independent deflate streams, so the reader threads inflate them in
+// parallel straight into the pinned slice (each member's place is known from the ISIZE trailers before anything is inflated).
 // Every buffer has HEAD spare bytes in front of the slice, where the consumer parks the unfinished line of the
 // slice before.
 class TextFeeder {
   public:
     static constexpr size_t HEAD = 1u << 20;
+    // threads: readers of a plain file; inflate_threads (>= threads is used): inflaters of a BGZF file
     TextFeeder(const std::string &path, size_t slice_bytes, size_t ring, size_t threads, void *(*alloc)(size_t),
-               void (*release)(void *));
+               void (*release)(void *), size_t inflate_threads = 0);
     ~TextFeeder();
     // blocks until slice k (k = 0, 1, 2, ... in order) is in its buffer; eof = this is the last slice
     bool acquire(size_t k, uint8_t *&data, size_t &len, uint64_t &newlines, bool &eof);
     uint8_t *buffer_of(size_t k) const { return bufs[k % ring_n]; }     // base of slice k's buffer (slice data at + HEAD)
     void release_below(size_t k);       // the buffers of slices < k may be refilled
     uint8_t first_byte = 0;             // first byte of the text
-    bool is_gz = false;
+    bool is_gz = false, is_bgzf = false;
     size_t file_size = 0, n_threads = 1;
     double busy_s = 0, wait_s = 0;      // Σ reader busy time; time the consumer waited for text
   private:
     struct Slot { size_t index = (size_t)-1, len = 0, pending = 0; uint64_t newlines = 0; bool ready = false, eof = false; };
+    struct BlockRef { size_t in_off; uint32_t in_len, out_off, out_len, crc; };     // one BGZF member: deflate bytes in the file -> place in the slice
     void run_plain();
     void run_gz();
+    void run_bgzf();
+    void plan_bgzf_slice(size_t k);      // under the lock: the members of slice k, from scan_off on
     void shutdown();
+    const uint8_t *map = nullptr;        // BGZF: the compressed file, memory-mapped
+    size_t scan_off = 0, planned = 0;    // BGZF: next member to plan; slices planned so far
+    std::vector<std::vector<BlockRef>> plans;
     std::string path;
     void (*free_fn)(void *);
     int fd = -1;

@@ -137,7 +137,7 @@ int sgh_text_feeder_walk(const char *path, uint64_t slice_bytes, uint64_t thread
                          uint64_t *lines_out, uint64_t *fnv_out, int *first_byte_out, int *is_gz_out) {
     return guard([&] {
         sgh::TextFeeder feed(path, (size_t)slice_bytes, 3, (size_t)threads, malloc, free);
-        *first_byte_out = feed.first_byte; *is_gz_out = feed.is_gz;
+        *first_byte_out = feed.first_byte; *is_gz_out = (feed.is_gz ? 1 : 0) | (feed.is_bgzf ? 2 : 0);
         uint64_t parts = 0, bytes = 0, first_line = 0, h = 1469598103934665603ull;
         size_t carry = 0;
         for (size_t k = 0;; k++) {

@@ -119,12 +119,13 @@ def fastx_stats(path):
 
 def text_feeder_walk(path, slice_bytes=1 << 16, threads=3):
     """Walks a file through the text path's byte source (TextFeeder) exactly as count() does and returns
-    (parts, bytes, lines, fnv1a-64 of all pushed bytes, first byte, is_gz)."""
+    (parts, bytes, lines, fnv1a-64 of all pushed bytes, first byte, is_gz) — is_gz is "bgzf" for a BGZF file (gzip members
+    inflated in parallel)."""
     parts, nbytes, lines, fnv = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
     fb, gz = C.c_int(), C.c_int()
     _chk(load().sgh_text_feeder_walk(path.encode(), C.c_uint64(slice_bytes), C.c_uint64(threads), C.byref(parts), C.byref(nbytes),
                                      C.byref(lines), C.byref(fnv), C.byref(fb), C.byref(gz)))
-    return parts.value, nbytes.value, lines.value, fnv.value, fb.value, bool(gz.value)
+    return parts.value, nbytes.value, lines.value, fnv.value, fb.value, ("bgzf" if gz.value & 2 else bool(gz.value))
 
 
 def cli(argv):

@@ -175,6 +175,28 @@ def test_stats_json_and_plain_text_pipeline(cli, tmp_path, example_library_text,
     assert s0["text_bytes"] == len(text) and st["total_s"] > 0 and s0["ingest_kernels_ms"] > 0 and s0["count_kernels_ms"] > 0
 
 
+def test_bgzf_input_is_inflated_in_parallel(cli, tmp_path, example_library_text, example_reads):
+    """A BGZF-compressed FASTQ (gzip members with a 'BC' size field) goes through the multi-threaded inflate of the text
+    path: same table as the oracle on the plain text; --stats-json says so."""
+    import json
+    from sgcount_amd.bgzf import bgzf_bytes
+    text = example_reads["diff.sequence"] * 40
+    p = os.path.join(str(tmp_path), "diff.fastq.gz")
+    open(p, "wb").write(bgzf_bytes(text, block=20000))
+    stats = os.path.join(str(tmp_path), "stats.json")
+    rc, out, err = run(cli, "-l", LIB, "-i", p, "-a", "5", "-q", "--io-threads", "4", "--chunk-mb", "0", "--stats-json", stats)
+    assert rc == 0, err
+    assert out == oracle_table(example_library_text, [text], ["diff"], [(False, 5)], False, True)
+    s0 = json.load(open(stats))["samples"][0]
+    assert s0["text_path"] and s0["gz"] and s0["bgzf"] and s0["reads"] == 1101 * 40 and s0["reader_threads"] == 4
+    # a corrupt member is an error, not a silent miscount
+    blob = bytearray(open(p, "rb").read())
+    blob[len(blob) // 2] ^= 0x55
+    open(p, "wb").write(bytes(blob))
+    rc, out, err = run(cli, "-l", LIB, "-i", p, "-a", "5", "-q")
+    assert rc != 0 and ("BGZF" in err or "read error" in err)      # whichever reader meets the bad member first
+
+
 def test_malformed_fastq_panics_like_the_reference(cli, tmp_path, example_reads):
     """fxread panics on a malformed record (unpinned): exit code 101, on the text path (GPU-verified marker
     bytes) and on the record-reader path alike; a truncated last record too."""

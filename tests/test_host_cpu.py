@@ -207,3 +207,38 @@ def test_text_feeder_delivers_every_byte_once(tmp_path):
     empty = tmp_path / "empty.fastq"
     empty.write_bytes(b"")
     assert hostlib.text_feeder_walk(str(empty))[:3] == (0, 0, 0)
+
+
+def test_text_feeder_inflates_bgzf_members_in_parallel(tmp_path):
+    """A BGZF file goes through several inflating threads (members are independent deflate streams placed by their ISIZE
+    trailers): same bytes, same order, right newline counts; members of uneven size, no end-of-file marker, a corrupt member."""
+    import gzip
+    import random
+    from sgcount_amd import hostlib
+    from sgcount_amd.bgzf import bgzf_bytes
+    rng = random.Random(5)
+    recs = []
+    for i in range(6000):
+        n = rng.choice([0, 1, 20, 90, 150, 400])
+        recs.append(b"@r%d\n%s\n+\n%s\n" % (i, bytes(rng.choice(b"ACGTN") for _ in range(n)), bytes(rng.choice(b"@+I#5") for _ in range(n))))
+    text = b"".join(recs)
+
+    def fnv(b):
+        h = 1469598103934665603
+        for c in b:
+            h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+    for body, block, marker in ((text, 65280, True), (text[:-1], 4000, False), (text, 65536, True), (text[:70000], 100, True)):
+        want = (len(body), body.count(b"\n") + (0 if body.endswith(b"\n") else 1), fnv(body))
+        p = tmp_path / "t.fastq.gz"
+        blob = bgzf_bytes(body, block, eof_marker=marker)
+        p.write_bytes(blob)
+        assert gzip.decompress(blob) == body                     # it is ordinary multi-member gzip too
+        for slice_bytes, threads in ((1 << 16, 1), (1 << 16, 4), (200_000, 3), (1 << 22, 8)):
+            parts, nbytes, lines, h, first, flag = hostlib.text_feeder_walk(str(p), slice_bytes, threads)
+            assert (nbytes, lines, h) == want and first == ord("@") and flag == "bgzf", (block, slice_bytes, threads)
+    bad = bytearray(bgzf_bytes(text, 30000))
+    bad[len(bad) // 2] ^= 0x55
+    (tmp_path / "bad.fastq.gz").write_bytes(bytes(bad))
+    with pytest.raises(hostlib.HostError):
+        hostlib.text_feeder_walk(str(tmp_path / "bad.fastq.gz"), 1 << 16, 4)
