@@ -195,6 +195,11 @@ void sgc_free_pinned(void *p);
 int sgc_set_option(sgc_ctx *, const char *key, int64_t value);
 
 /* ---- diagnostics -------------------------------------------------------------------------------- */
+/* Builds the host-side tables of a library exactly as sgc_set_library would (no device needed) and checks that every guide
+ * is reachable where the kernels look for it: the open-addressed array, the two-choice image of the slices, or — for a
+ * library of arbitrary bytes / L > 30 — the byte-string table.  stats[4]: [0] = 1 packed path, 2 byte-string path;
+ * [1] = library slots; [2] = single-mismatch entries (0 unless enable_1mm); [3] = 1 if the two-choice image was built. */
+int sgc_check_host_tables(const uint8_t *seqs, uint32_t n, uint32_t L, int enable_1mm, uint64_t *stats);
 int sgc_timing_enable(sgc_ctx *, int on);     /* record HIP events around every kernel (adds a sync at read) */
 int sgc_timing_read(sgc_ctx *, sgc_timing *out, int reset);
 const char *sgc_last_error(void);

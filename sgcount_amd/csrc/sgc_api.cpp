@@ -991,6 +991,74 @@ int sgc_sample_finish(sgc_sample *s, uint64_t *counts, uint64_t *total_reads, ui
     return check_fastq_errors(s);
 }
 
+// Host-side self-check of the table builders (no device needed): every guide must be found where the kernels will look.
+int sgc_check_host_tables(const uint8_t *seqs, uint32_t n, uint32_t L, int enable_1mm, uint64_t *stats) {
+    if (!seqs || !stats) return fail(SGC_E_ARG, "sgc_check_host_tables: NULL argument");
+    memset(stats, 0, 4 * sizeof(uint64_t));
+    std::string err;
+    std::vector<uint64_t> keys;
+    sgc_host_table h;
+    const uint32_t want_cl = (L >= 4 && L <= SGC_REC8_MAXL) ? (L - 2) / 2 : 0;
+    int rc = sgc_build_library_table(seqs, n, L, SGC_LDS_LOG2_SLICE, want_cl, keys, h, err);
+    if (rc == SGC_E_UNSUPPORTED && L >= 1 && n >= 1) {
+        // byte-string tables (sgc_bytes.h): probe the library table for every guide, the children table for every stored child
+        sgc_host_bytes hb;
+        rc = sgc_build_bytes_tables(seqs, n, L, enable_1mm != 0, hb, err);
+        if (rc != SGC_OK) return fail(rc, "sgc_check_host_tables: " + err);
+        const uint32_t lmask = (1u << hb.lib_log2) - 1u;
+        for (uint32_t g = 0; g < n; g++) {
+            uint64_t hsh = sgc_bytes_hash_init();
+            for (uint32_t i = 0; i < L; i++) hsh = sgc_bytes_hash_step(hsh, seqs[(size_t)g * L + i]);
+            hsh = sgc_bytes_hash_fin(hsh);
+            bool found = false;
+            for (uint32_t s = sgc_bytes_slot(hsh, hb.lib_log2); hb.lib_tag[s] != SGC_BYTES_EMPTY && !found; s = (s + 1) & lmask)
+                found = hb.lib_tag[s] == hsh && hb.lib_val[s] == g;
+            if (!found) return fail(SGC_E_STATE, "sgc_check_host_tables: guide " + std::to_string(g) + " is not reachable in the byte-string table");
+        }
+        stats[0] = 2; stats[1] = (uint64_t)1 << hb.lib_log2; stats[2] = hb.perm_entries;
+        return SGC_OK;
+    }
+    if (rc != SGC_OK) return fail(rc, "sgc_check_host_tables: " + err);
+    stats[0] = 1; stats[1] = (uint64_t)1 << h.log2_slots;
+    const uint32_t S = 1u << h.log2_slice;
+    // the open-addressed array: scan from the home bucket inside the slice
+    for (uint32_t g = 0; g < n; g++) {
+        uint32_t b = sgc_home_bucket_ex(keys[g], h.log2_slots, h.log2_slice, h.core_cl);
+        bool found = false;
+        for (uint32_t step = 0; step < S && !found; step++) {
+            for (uint32_t k = 0; k < 2; k++) {
+                const uint64_t e = h.slots[2 * (size_t)b + k];
+                if (e != SGC_EMPTY && h.gid_bits && (e >> h.gid_bits) == keys[g]) found = (uint32_t)(e & ((1ull << h.gid_bits) - 1ull)) == g;
+                if (e != SGC_EMPTY && !h.gid_bits && e == keys[g]) found = h.vals[2 * (size_t)b + k] == g;
+            }
+            b = sgc_next_bucket(b, h.log2_slice);
+        }
+        if (!found) return fail(SGC_E_STATE, "sgc_check_host_tables: guide " + std::to_string(g) + " is not reachable in the library table");
+    }
+    // the two-choice image of the slices (k_count_slices): home slot or its alternate, nowhere else
+    std::vector<uint64_t> ck;
+    if (h.gid_bits && h.log2_slice <= SGC_LDS_LOG2_SLICE && sgc_build_slice_cuckoo(h, ck)) {
+        stats[3] = 1;
+        for (uint32_t g = 0; g < n; g++) {
+            const uint32_t hs = sgc_home_slot_ex(keys[g], h.log2_slots, h.log2_slice, h.core_cl);
+            const size_t base = (size_t)(hs >> h.log2_slice) * S;
+            const uint32_t s1 = hs & (S - 1u), s2 = sgc_cuckoo_alt(keys[g], s1, h.log2_slice);
+            const uint64_t want = (keys[g] << h.gid_bits) | g;
+            if (ck[base + s1] != want && ck[base + s2] != want)
+                return fail(SGC_E_STATE, "sgc_check_host_tables: guide " + std::to_string(g) + " is in neither of its two slots");
+        }
+        uint64_t occupied = 0;
+        for (uint64_t e : ck) occupied += e != SGC_EMPTY;
+        if (occupied != n) return fail(SGC_E_STATE, "sgc_check_host_tables: the two-choice image holds " + std::to_string(occupied) + " entries");
+    }
+    if (enable_1mm) {
+        sgc_host_table hp;
+        sgc_build_permute_table(keys, L, h, hp, nullptr, nullptr);
+        stats[2] = hp.entries;
+    }
+    return SGC_OK;
+}
+
 int sgc_timing_enable(sgc_ctx *c, int on) {
     if (!c) return fail(SGC_E_ARG, "sgc_timing_enable: NULL");
     c->timing = on != 0;

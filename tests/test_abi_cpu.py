@@ -94,3 +94,36 @@ def test_status_division_magic():
     for K in range(3, 26):
         m = (1 << 20) // K + 1
         assert all(((n * m) >> 20) == n // K for n in range(K ** 3)), K
+
+
+@pytest.mark.parametrize("n,L,alpha", [(100_000, 20, b"ACGT"), (5_000, 23, b"ACGT"), (300, 12, b"ACGT"), (2, 4, b"ACGT"),
+                                      (40_000, 20, b"ACGTN"), (3_000, 34, b"ACGT"), (5, 1, b"ACGTN")])
+def test_host_tables_reach_every_guide(n, L, alpha):
+    """sgc_check_host_tables: the tables sgc_set_library would upload, built on the host and probed the way the kernels probe
+    them — the open-addressed array (home bucket, wrap inside the slice), the one-slot two-choice image that k_count_slices
+    stages in LDS (home slot or its alternate), and for libraries outside ACGT / longer than 30 the byte-string tables."""
+    import ctypes as C
+    ffi = _ffi()
+    lib = ffi.load()
+    rng = np.random.default_rng(n + L)
+    seqs = set()
+    while len(seqs) < n:
+        need = n - len(seqs)
+        draw = rng.integers(0, len(alpha), size=(need + 16, L))
+        for row in np.frombuffer(alpha, dtype=np.uint8)[draw]:
+            seqs.add(row.tobytes())
+            if len(seqs) == n:
+                break
+    flat = b"".join(sorted(seqs))
+    stats = (C.c_uint64 * 4)()
+    rc = lib.sgc_check_host_tables(flat, n, L, 1 if n <= 5000 else 0, stats)
+    assert rc == 0, lib.sgc_last_error()
+    packed = set(alpha) <= set(b"ACGT") and L <= 30
+    assert stats[0] == (1 if packed else 2)
+    if packed:
+        assert stats[1] >= 2 * n and stats[3] == 1          # load <= 0.5; the two-choice image was placed
+    elif n <= 5000:
+        assert stats[2] <= n * L * 4 and (stats[2] > 0 or L == 1)   # children stored (all five 1-mers: every child is a guide)
+    # a duplicate sequence is reported as such by both builders
+    dup = flat[:L] * 2
+    assert lib.sgc_check_host_tables(dup, 2, L, 0, stats) == ffi.E_DUPLICATE
