@@ -45,6 +45,7 @@ struct sgc_ctx {
     uint64_t *d_lib_slots = nullptr, *d_perm_slots = nullptr, *d_lib_cuckoo = nullptr;
     bool dense = true;                 // k_count_slices writes its misses as dense runs (no per-group barrier) instead of in place
     bool direct = true;                // ... one run per partition of core pass A, consumed where it lies (needs dense + tag_sub)
+    bool six_byte = true;              // ... and the slice blocks hold six-byte records (needs direct, L <= 21)
     bool tag_sub = true;               // K1 tags the pass-A partition inside the slice, K2 counts misses by it (no histogram sweep)
     bool use_cuckoo = true;            // k_count_slices probes the two-choice image of the slices (no chain loop)
     uint32_t *d_lib_vals = nullptr, *d_perm_vals = nullptr;
@@ -199,13 +200,15 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
             const int sub = (int)c->v_core[0].log2_p - ((int)c->v_lib.log2_slots - (int)c->v_lib.log2_slice);
             const bool tag_sub = core_path && c->tag_sub && c->v_lib.core_cl == c->v_core[0].cl && c->v_lib.log2_slice < c->v_lib.log2_slots &&
                                  sub >= 0 && sub <= 2;
-            { timed t(c, T_PART); sgc_launch_part_k1(c->stream, p, chunk, c->L, c->v_lib, tag_sub ? (uint32_t)sub : 0u, g, pool, desc); }
+            // direct runs: the misses go straight to per-partition runs inside one allocation with pass A's other input
+            // (runs region | miss runs | forward buffer); the run matrices get one more column per workgroup of a slice.
+            // With them nothing but the probe loop reads the slice blocks, which then hold six-byte records if they fit.
+            const bool direct = core_path && c->dense && c->direct && tag_sub && sgc_part_k2_grid(g) + sgc_part_k2_shares(g) <= 1024u;
+            const bool six = direct && c->six_byte && 2u * (c->L + 2u) + 2u <= 48u;
+            { timed t(c, T_PART); sgc_launch_part_k1(c->stream, p, chunk, c->L, c->v_lib, tag_sub ? (uint32_t)sub : 0u, g, pool, desc, six); }
             if (core_path) {
                 // everything the slice probe does not settle (its misses + the generic partition) is resolved in LDS by the
                 // two core passes; k_count_slices itself lays those records out as pass A's runs
-                // direct runs: the misses go straight to per-partition runs inside one allocation with pass A's other input
-                // (runs region | miss runs | forward buffer); the run matrices get one more column per workgroup of a slice
-                const bool direct = c->dense && c->direct && tag_sub && sgc_part_k2_grid(g) + sgc_part_k2_shares(g) <= 1024u;
                 sgc_core_geometry cg;
                 sgc_core_plan(chunk, c->v_core[0], c->v_core[1], sgc_part_k2_grid(g) + (direct ? sgc_part_k2_shares(g) : 0u), &cg);
                 const size_t mrun_bytes = c->dense ? (size_t)g.pool_bytes << (direct ? (uint32_t)sub : 0u) : 0;
@@ -220,7 +223,7 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
                 if (tag_sub) ra.sub_bits = (uint32_t)sub;
                 uint32_t *mcur = (uint32_t *)zeroed + 2 * RUN_MAXP + 2;        // behind totals A | totals B | region cursors (zeroed by K1)
                 { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg, &ra,
-                                                                 c->use_cuckoo ? c->d_lib_cuckoo : nullptr, mrun, mcur, direct); }
+                                                                 c->use_cuckoo ? c->d_lib_cuckoo : nullptr, mrun, mcur, direct, six); }
                 // timing: miss_ms = core pass A (+ its epilogue), hist_ms = core pass B
                 if (!c->one_mm) {
                     timed t(c, T_MISS, true);
@@ -238,7 +241,7 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
                 if (done < n) { sgc_launch_fold(c->stream, s->d_c32, s->d_c64, c->n); s->since_fold = 0; }
                 continue;
             }
-            { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg, nullptr, c->use_cuckoo ? c->d_lib_cuckoo : nullptr, nullptr, nullptr, false); }
+            { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg, nullptr, c->use_cuckoo ? c->d_lib_cuckoo : nullptr, nullptr, nullptr, false, false); }
             rc = ensure(&c->d_gids, &c->gids_cap, g.gids_bytes);                // one slot per pool record: every read may miss
             if (rc) return rc;
             rc = ensure(&c->d_aux, &c->aux_cap, ((size_t)g.n_segs + 1) * 4);
@@ -441,6 +444,7 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
     if (!strcmp(key, "force_bytes")) { c->force_bytes = value != 0; return SGC_OK; }         // takes effect at the next sgc_set_library
     if (!strcmp(key, "dense")) { c->dense = value != 0; return SGC_OK; }
     if (!strcmp(key, "direct")) { c->direct = value != 0; return SGC_OK; }
+    if (!strcmp(key, "six_byte")) { c->six_byte = value != 0; return SGC_OK; }
     if (!strcmp(key, "tag_sub")) { c->tag_sub = value != 0; return SGC_OK; }
     if (!strcmp(key, "cuckoo")) { c->use_cuckoo = value != 0; return SGC_OK; }
     if (!strcmp(key, "rest_filter")) { c->rest_filter = value != 0; return SGC_OK; }         // takes effect at the next sgc_set_library

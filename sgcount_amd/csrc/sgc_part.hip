@@ -65,10 +65,19 @@ __device__ __forceinline__ uint32_t part_front(uint32_t b) { return ((b * 265443
 // partitions of core pass A that refine it, so the epilogue of k_count_slices writes a handful of streams, not hundreds.
 // sub_bits (0..2, only with core-hashed slices): the next bits of the core hash below the slice — the partition of core
 // pass A inside the slice — ride along too, so that k_count_slices can count its misses by that partition as it goes.
+// p6 (six-byte slice blocks, below): the home slot is not tagged (k_count_slices hashes the key again: one multiply) and the
+// sub-partition sits right above the span, so that a clean record is 2 (L + 2) + 2 <= 48 bits.
 __device__ __forceinline__ uint32_t part_of(uint64_t &rec, uint64_t kmask, uint32_t sh, uint32_t log2_slots,
-                                            uint32_t log2_slice, uint32_t core_cl, uint32_t sub_bits) {
+                                            uint32_t log2_slice, uint32_t core_cl, uint32_t sub_bits, bool p6) {
     if ((rec >> sh) != 0) return 1u << (log2_slots - log2_slice);
     const uint64_t key = (rec >> 2) & kmask;
+    if (p6) {
+        // core-hashed slices (sgc_home_slot_ex with core_cl > 0): the slice and the sub-partition are prefixes of ONE hash
+        const uint32_t hc = sgc_core_hash((uint32_t)((key >> 2) & ((1ull << (2 * core_cl)) - 1ull)));
+        const uint32_t part = sgc_core_part(hc, log2_slots - log2_slice + sub_bits);
+        rec |= (uint64_t)(part & ((1u << sub_bits) - 1u)) << sh;
+        return part >> sub_bits;
+    }
     const uint32_t hs = sgc_home_slot_ex(key, log2_slots, log2_slice, core_cl);
     uint64_t tag = (uint64_t)(hs & ((1u << log2_slice) - 1u)) << PART_TAG_SHIFT;
     if (sub_bits) {
@@ -79,13 +88,19 @@ __device__ __forceinline__ uint32_t part_of(uint64_t &rec, uint64_t kmask, uint3
     return hs >> log2_slice;
 }
 
+// Six-byte slice blocks (p6; only with the direct-run path, where nothing but k_count_slices' probe loop reads them): a
+// block of 1024 clean records is 1024 x u32 (low words) followed by 1024 x u16 (bits 32..47) in the first 6 KiB of its
+// 8 KiB stride — a quarter less to write here and to read there, and both kernels run at what the memory system gives
+// this access pattern.  Blocks of the generic partition keep whole 8-byte records (their status does not fit).
+#define P6_HI_OFF 4096u
+
 // ------------------------------------------------------------------------------------------------ K1
 __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__restrict__ recs, uint64_t n, uint64_t per_wg,
                                                    uint32_t blocks_per_wg, uint32_t L, uint32_t log2_slots,
                                                    uint32_t log2_slice, uint32_t core_cl, uint32_t sub_bits, uint64_t *__restrict__ pool,
                                                    uint32_t *__restrict__ desc, uint32_t *__restrict__ tail,
                                                    uint32_t tail_words, uint32_t *__restrict__ wcnt,
-                                                   uint32_t *__restrict__ wlist) {
+                                                   uint32_t *__restrict__ wlist, uint32_t p6) {
     __shared__ uint64_t stage[PART_TILE];
     __shared__ uint8_t stage_p[PART_TILE];               // partition of every staged record
     __shared__ uint32_t cnt[PART_ARR], start[PART_ARR], blk[PART_ARR], fill[PART_ARR];
@@ -117,7 +132,7 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
         for (uint32_t k = 0; k < PART_TILE / K1_THREADS; k++) {
             const uint32_t j = k * K1_THREADS + t;
             if (j < m) {
-                const uint32_t p = part_of(rec[k], kmask, sh, log2_slots, log2_slice, core_cl, sub_bits);
+                const uint32_t p = part_of(rec[k], kmask, sh, log2_slots, log2_slice, core_cl, sub_bits, p6 != 0);
                 pr[k] = (p << 16) | atomicAdd(&cnt[p], 1u);
             }
         }
@@ -191,7 +206,14 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
             const uint32_t p = stage_p[j];
             const uint32_t rank = j - start[p];
             const uint64_t at = rank < split[p] ? (uint64_t)dst_a[p] + rank : (uint64_t)dst_b[p] + (rank - split[p]);
-            pool[at] = r;
+            if (p6 && p != P) {
+                char *bb = reinterpret_cast<char *>(pool) + (at >> 10) * (PART_BLOCK * 8u);
+                const uint32_t idx = (uint32_t)at & (PART_BLOCK - 1u);
+                reinterpret_cast<uint32_t *>(bb)[idx] = (uint32_t)r;
+                reinterpret_cast<uint16_t *>(bb + P6_HI_OFF)[idx] = (uint16_t)(r >> 32);
+            } else {
+                pool[at] = r;
+            }
         }
         __syncthreads();
     }
@@ -213,6 +235,16 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
 //                 // blocks per group: one group is processed while the next is in flight
 #define K2_SCAN 16u              // descriptors examined per lane per scan chunk
 #define K2_GLIST 64u             // generic blocks listed per epilogue window
+// record j of slice block b
+template <bool P6>
+__device__ __forceinline__ uint64_t k2_record(const uint64_t *__restrict__ pool, uint32_t b, uint32_t j) {
+    if (!P6) return pool[(uint64_t)b * PART_BLOCK + j];
+    const char *bb = reinterpret_cast<const char *>(pool) + (uint64_t)b * (PART_BLOCK * 8u);
+    const uint32_t lo = reinterpret_cast<const uint32_t *>(bb)[j];
+    const uint32_t hi = reinterpret_cast<const uint16_t *>(bb + P6_HI_OFF)[j];
+    return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
 // CUCKOO: the slice is staged from its two-choice image (`cuck`, sgc_format.h sgc_cuckoo_alt): both candidate slots are
 // read at once (two 8-byte LDS reads) and the probe has no loop.
 // DENSE (only with ep.recs): the misses do not go back into their blocks but, densely, into a stretch of `mrun` the workgroup
@@ -226,7 +258,8 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
 // its slice) of the run matrices, nothing is read back or moved.  Only the workgroup's share of the generic blocks still goes
 // through the epilogue's histogram + placement, as producer column G + blockIdx.x.  mrun must be ep.recs + (an offset that
 // fits 32 bits); ep.W = G + gridDim.x.
-template <int LOG2_SLICE, bool CUCKOO, bool DENSE, bool DIRECT>
+// P6 (with DIRECT): the slice blocks hold six-byte records (k_partition, P6_HI_OFF).
+template <int LOG2_SLICE, bool CUCKOO, bool DENSE, bool DIRECT, bool P6>
 __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(80))) k_count_slices(uint64_t *__restrict__ pool, uint32_t *__restrict__ desc,
                                                              const uint32_t *__restrict__ wcnt, const uint32_t *__restrict__ wlist,
                                                              uint32_t k1_wgs, uint32_t blocks_per_wg, uint32_t G, uint32_t L,
@@ -302,7 +335,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             for (uint32_t k = 0; k < RPT; k++) {
                 const uint32_t j = k * K2_THREADS + t;
                 // lanes past the block's fill have nothing to read (one open block per K1 workgroup and slice is part empty)
-                cur[u * RPT + k] = (ce[u] != 0xFFFFFFFFu && j <= (ce[u] & 2047u)) ? pool[(uint64_t)(ce[u] >> 11) * PART_BLOCK + j] : 0ull;
+                cur[u * RPT + k] = (ce[u] != 0xFFFFFFFFu && j <= (ce[u] & 2047u)) ? k2_record<P6>(pool, ce[u] >> 11, j) : 0ull;
             }
         }
         for (uint32_t li = 0; li < nl; li += K2_U) {
@@ -322,7 +355,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
 #pragma unroll
                 for (uint32_t k = 0; k < RPT; k++) {
                     const uint32_t j = k * K2_THREADS + t;
-                    nxt[u * RPT + k] = (ne != 0xFFFFFFFFu && j <= (ne & 2047u)) ? pool[(uint64_t)(ne >> 11) * PART_BLOCK + j] : 0ull;
+                    nxt[u * RPT + k] = (ne != 0xFFFFFFFFu && j <= (ne & 2047u)) ? k2_record<P6>(pool, ne >> 11, j) : 0ull;
                 }
             }
             // Centered-exact probe (src/counter.rs:111) of the Q records against the slice in LDS.  The LDS copy
@@ -336,7 +369,8 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 const uint32_t u = q / RPT, j = (q % RPT) * K2_THREADS + t;
                 const bool valid = ce[u] != 0xFFFFFFFFu && j <= (ce[u] & 2047u);
                 const uint64_t key = (cur[q] >> 2) & kmask;
-                const uint32_t s1 = (uint32_t)(cur[q] >> PART_TAG_SHIFT);    // home slot inside the slice, left there by k_partition
+                // home slot inside the slice: left there by k_partition, or (six-byte records) hashed again here
+                const uint32_t s1 = P6 ? sgc_hash32(key) >> (32u - ls) : (uint32_t)(cur[q] >> PART_TAG_SHIFT);
                 uint32_t b = s1 >> 1, slot;
                 ulonglong2 wv;
                 bool hit;
@@ -367,9 +401,9 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 // histogram sweep does not have to read the fronts once more
                 if (count_sub && !DIRECT) atomicAdd(mv ? &hn[(p << ep.sub_bits) | ((uint32_t)(cur[q] >> PART_SUB_SHIFT) & 3u)] : &scratch[t & 63u], 1u);
                 if (DIRECT) {
-                    const uint32_t sub = (uint32_t)(cur[q] >> PART_SUB_SHIFT) & 3u;
+                    const uint32_t sub = (uint32_t)(cur[q] >> (P6 ? 2u * (L + 2u) : PART_SUB_SHIFT)) & 3u;
                     const uint32_t pos = atomicAdd(mv ? &wmiss4[sub] : &scratch[64u + (t & 63u)], 1u);
-                    if (mv) mrun[(uint64_t)run0 + sub * stretch + pos] = cur[q] & PART_TAG_MASK;
+                    if (mv) mrun[(uint64_t)run0 + sub * stretch + pos] = cur[q] & (P6 ? (1ull << (2u * (L + 2u))) - 1ull : PART_TAG_MASK);
                 } else if (DENSE) {
                     // (a ballot + one atomic by the lowest missing lane measured 0.02 ms slower than this predicated add)
                     const uint32_t pos = atomicAdd(mv ? &wmiss : &scratch[64u + (t & 63u)], 1u);
@@ -776,10 +810,10 @@ void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_
 }
 
 void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib, uint32_t sub_bits,
-                        const sgc_part_geometry &g, uint64_t *pool, uint32_t *desc) {
+                        const sgc_part_geometry &g, uint64_t *pool, uint32_t *desc, bool six_byte) {
     hipLaunchKernelGGL(k_partition, dim3(g.k1_wgs), dim3(K1_THREADS), 0, st, recs, n, g.per_wg, g.blocks_per_wg, L,
                        lib.log2_slots, lib.log2_slice, lib.core_cl, sub_bits, pool, desc, (uint32_t *)((char *)desc + g.desc_tail_off), SGC_DESC_TAIL / 4,
-                       (uint32_t *)((char *)desc + g.wcnt_off), (uint32_t *)((char *)desc + g.wlist_off));
+                       (uint32_t *)((char *)desc + g.wcnt_off), (uint32_t *)((char *)desc + g.wlist_off), six_byte ? 1u : 0u);
 }
 
 // workgroups of k_count_slices: G per slice, two per CU in all — one resident generation
@@ -789,17 +823,18 @@ uint32_t sgc_part_k2_shares(const sgc_part_geometry &g) { return k2_shares(g); }
 
 void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_part_geometry &g,
                         uint64_t *pool, uint32_t *desc, uint32_t *counts, unsigned long long *matched, uint32_t dbg,
-                        const sgc_runs *runs, const uint64_t *cuckoo, uint64_t *mrun, uint32_t *mcur, bool direct_runs) {
+                        const sgc_runs *runs, const uint64_t *cuckoo, uint64_t *mrun, uint32_t *mcur, bool direct_runs, bool six_byte) {
     const uint32_t G = k2_shares(g);
     sgc_runs none{};
     const uint32_t *wcnt = (const uint32_t *)((const char *)desc + g.wcnt_off), *wlist = (const uint32_t *)((const char *)desc + g.wlist_off);
     const bool dense = runs && mrun;
     const bool direct = dense && direct_runs && runs->sub_bits != 0xFFu;
-#define K2_LAUNCH(CK, DN, DR)                                                                                                          \
-    hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE, CK, DN, DR>), dim3(g.partitions * G), dim3(K2_THREADS), 0, st, pool, desc, wcnt, wlist, \
+#define K2_LAUNCH(CK, DN, DR, P6)                                                                                                      \
+    hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE, CK, DN, DR, P6>), dim3(g.partitions * G), dim3(K2_THREADS), 0, st, pool, desc, wcnt, wlist, \
                        g.k1_wgs, g.blocks_per_wg, G, L, lib, counts, matched, dbg, runs ? *runs : none, cuckoo, mrun, mcur)
-    if (cuckoo) { if (direct) K2_LAUNCH(true, true, true); else if (dense) K2_LAUNCH(true, true, false); else K2_LAUNCH(true, false, false); }
-    else { if (direct) K2_LAUNCH(false, true, true); else if (dense) K2_LAUNCH(false, true, false); else K2_LAUNCH(false, false, false); }
+    const bool p6 = direct && six_byte;
+    if (cuckoo) { if (p6) K2_LAUNCH(true, true, true, true); else if (direct) K2_LAUNCH(true, true, true, false); else if (dense) K2_LAUNCH(true, true, false, false); else K2_LAUNCH(true, false, false, false); }
+    else { if (p6) K2_LAUNCH(false, true, true, true); else if (direct) K2_LAUNCH(false, true, true, false); else if (dense) K2_LAUNCH(false, true, false, false); else K2_LAUNCH(false, false, false, false); }
 #undef K2_LAUNCH
 }
 
