@@ -65,27 +65,34 @@ __device__ __forceinline__ uint32_t part_front(uint32_t b) { return ((b * 265443
 // partitions of core pass A that refine it, so the epilogue of k_count_slices writes a handful of streams, not hundreds.
 // sub_bits (0..2, only with core-hashed slices): the next bits of the core hash below the slice — the partition of core
 // pass A inside the slice — ride along too, so that k_count_slices can count its misses by that partition as it goes.
-// p6 (six-byte slice blocks, below): the home slot is not tagged (k_count_slices hashes the key again: one multiply) and the
-// sub-partition sits right above the span, so that a clean record is 2 (L + 2) + 2 <= 48 bits.
-__device__ __forceinline__ uint32_t part_of(uint64_t &rec, uint64_t kmask, uint32_t sh, uint32_t log2_slots,
-                                            uint32_t log2_slice, uint32_t core_cl, uint32_t sub_bits, bool p6) {
-    if ((rec >> sh) != 0) return 1u << (log2_slots - log2_slice);
+// MODE (compile time: the per-record code has no branches and touches nothing but its own record — with run-time
+// modes the compiler copied the whole register tile around every branch, 32 moves per record):
+//   0  slices by the full-key hash (sgc_home_slot_ex with core_cl == 0, or one slice), 8-byte records, slot tag
+//   1  core-hashed slices, 8-byte records, slot tag + sub-partition tag
+//   2  core-hashed slices, six-byte records (below): the home slot is not tagged (k_count_slices hashes the key again:
+//      one multiply) and the sub-partition sits right above the span, so that a clean record is 2 (L + 2) + 2 <= 48 bits
+// Returns the partition; `tag` is what to OR into the record (0 for the generic partition).
+template <int MODE>
+__device__ __forceinline__ uint32_t part_of(uint64_t rec, uint64_t kmask, uint32_t sh, uint32_t log2_slots, uint32_t log2_slice,
+                                            uint32_t core_cl, uint32_t sub_bits, uint64_t &tag) {
+    const bool generic = (rec >> sh) != 0;
     const uint64_t key = (rec >> 2) & kmask;
-    if (p6) {
-        // core-hashed slices (sgc_home_slot_ex with core_cl > 0): the slice and the sub-partition are prefixes of ONE hash
+    uint32_t p;
+    if (MODE == 0) {
+        const uint32_t hs = (uint32_t)(sgc_hash(key) >> (64 - log2_slots));
+        tag = (uint64_t)(hs & ((1u << log2_slice) - 1u)) << PART_TAG_SHIFT;
+        p = hs >> log2_slice;
+    } else {
+        // the slice and the sub-partition are prefixes of ONE hash of the core-A bases (log2_slots > log2_slice here)
+        const uint32_t n = log2_slots - log2_slice;
         const uint32_t hc = sgc_core_hash((uint32_t)((key >> 2) & ((1ull << (2 * core_cl)) - 1ull)));
-        const uint32_t part = sgc_core_part(hc, log2_slots - log2_slice + sub_bits);
-        rec |= (uint64_t)(part & ((1u << sub_bits) - 1u)) << sh;
-        return part >> sub_bits;
+        const uint32_t part = hc >> (32u - n - sub_bits), sub = part & ((1u << sub_bits) - 1u);
+        p = part >> sub_bits;
+        if (MODE == 2) tag = (uint64_t)sub << sh;
+        else tag = ((uint64_t)(sgc_hash32(key) >> (32u - log2_slice)) << PART_TAG_SHIFT) | ((uint64_t)sub << PART_SUB_SHIFT);
     }
-    const uint32_t hs = sgc_home_slot_ex(key, log2_slots, log2_slice, core_cl);
-    uint64_t tag = (uint64_t)(hs & ((1u << log2_slice) - 1u)) << PART_TAG_SHIFT;
-    if (sub_bits) {
-        const uint32_t hc = sgc_core_hash((uint32_t)((key >> 2) & ((1ull << (2 * core_cl)) - 1ull)));
-        tag |= (uint64_t)(sgc_core_part(hc, log2_slots - log2_slice + sub_bits) & ((1u << sub_bits) - 1u)) << PART_SUB_SHIFT;
-    }
-    rec |= tag;
-    return hs >> log2_slice;
+    if (generic) { tag = 0; p = 1u << (log2_slots - log2_slice); }
+    return p;
 }
 
 // Six-byte slice blocks (p6; only with the direct-run path, where nothing but k_count_slices' probe loop reads them): a
@@ -95,12 +102,14 @@ __device__ __forceinline__ uint32_t part_of(uint64_t &rec, uint64_t kmask, uint3
 #define P6_HI_OFF 4096u
 
 // ------------------------------------------------------------------------------------------------ K1
+template <int MODE>
 __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__restrict__ recs, uint64_t n, uint64_t per_wg,
                                                    uint32_t blocks_per_wg, uint32_t L, uint32_t log2_slots,
                                                    uint32_t log2_slice, uint32_t core_cl, uint32_t sub_bits, uint64_t *__restrict__ pool,
                                                    uint32_t *__restrict__ desc, uint32_t *__restrict__ tail,
                                                    uint32_t tail_words, uint32_t *__restrict__ wcnt,
-                                                   uint32_t *__restrict__ wlist, uint32_t p6) {
+                                                   uint32_t *__restrict__ wlist) {
+    constexpr bool p6 = MODE == 2;
     __shared__ uint64_t stage[PART_TILE];
     __shared__ uint8_t stage_p[PART_TILE];               // partition of every staged record
     __shared__ uint32_t cnt[PART_ARR], start[PART_ARR], blk[PART_ARR], fill[PART_ARR];
@@ -132,7 +141,9 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
         for (uint32_t k = 0; k < PART_TILE / K1_THREADS; k++) {
             const uint32_t j = k * K1_THREADS + t;
             if (j < m) {
-                const uint32_t p = part_of(rec[k], kmask, sh, log2_slots, log2_slice, core_cl, sub_bits, p6 != 0);
+                uint64_t tag;
+                const uint32_t p = part_of<MODE>(rec[k], kmask, sh, log2_slots, log2_slice, core_cl, sub_bits, tag);
+                rec[k] |= tag;
                 pr[k] = (p << 16) | atomicAdd(&cnt[p], 1u);
             }
         }
@@ -811,9 +822,15 @@ void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_
 
 void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib, uint32_t sub_bits,
                         const sgc_part_geometry &g, uint64_t *pool, uint32_t *desc, bool six_byte) {
-    hipLaunchKernelGGL(k_partition, dim3(g.k1_wgs), dim3(K1_THREADS), 0, st, recs, n, g.per_wg, g.blocks_per_wg, L,
-                       lib.log2_slots, lib.log2_slice, lib.core_cl, sub_bits, pool, desc, (uint32_t *)((char *)desc + g.desc_tail_off), SGC_DESC_TAIL / 4,
-                       (uint32_t *)((char *)desc + g.wcnt_off), (uint32_t *)((char *)desc + g.wlist_off), six_byte ? 1u : 0u);
+    const bool core_hashed = lib.core_cl != 0 && lib.log2_slice < lib.log2_slots;
+#define K1_LAUNCH(MODE)                                                                                                            \
+    hipLaunchKernelGGL((k_partition<MODE>), dim3(g.k1_wgs), dim3(K1_THREADS), 0, st, recs, n, g.per_wg, g.blocks_per_wg, L,          \
+                       lib.log2_slots, lib.log2_slice, lib.core_cl, sub_bits, pool, desc, (uint32_t *)((char *)desc + g.desc_tail_off), \
+                       SGC_DESC_TAIL / 4, (uint32_t *)((char *)desc + g.wcnt_off), (uint32_t *)((char *)desc + g.wlist_off))
+    if (six_byte && core_hashed) K1_LAUNCH(2);
+    else if (core_hashed) K1_LAUNCH(1);
+    else K1_LAUNCH(0);
+#undef K1_LAUNCH
 }
 
 // workgroups of k_count_slices: G per slice, two per CU in all — one resident generation

@@ -7,7 +7,7 @@ import sys
 want = sys.argv[2:] if len(sys.argv) > 2 else None
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(sys.argv[1])):
-    name = r["Kernel_Name"].split("(")[0][-40:]
+    name = r["Kernel_Name"].split("(")[0].replace("void ", "")[:64]
     acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for name, cs in acc.items():
     if want and not any(w in name for w in want):
