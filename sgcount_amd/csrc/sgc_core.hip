@@ -74,11 +74,22 @@ __device__ __forceinline__ void starts_from_totals(const uint32_t *__restrict__ 
 // EXACT (with FINAL): the -x mode (src/count.rs:103-107: no Permuter).  Only the exact levels exist, and a guide that equals a
 // window agrees with it on BOTH cores, so ONE pass over core A settles everything k_count_slices left: Plus-exact and
 // Minus-exact (src/counter.rs:123-130).  A window with an 'N' cannot equal an ACGT guide: invisible.
-template <bool FINAL, bool EXACT>
+// LT: the guide length as a compile-time constant (20: what sgRNA libraries almost always are), or 0 = read it from the
+// arguments.  With LT the shifts, masks and core geometry of the per-record code are immediates instead of two dozen scalar
+// registers — the kernel is capped at 80 (more would halve the occupancy of its 1024-lane workgroups) and was restoring
+// spilled scalars with v_readlane all through its record loop.
+template <bool FINAL, bool EXACT, int LT>
 __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(80))) k_core(
-    const sgc_runs in, sgc_core_view cv, const ulonglong2 *__restrict__ amb, uint32_t L, sgc_table_view lib, sgc_table_view perm,
+    const sgc_runs in, sgc_core_view cv, const ulonglong2 *__restrict__ amb, uint32_t L_arg, sgc_table_view lib, sgc_table_view perm,
     uint64_t *__restrict__ fwd, const sgc_runs out, uint32_t *__restrict__ counts, unsigned long long *__restrict__ matched,
     uint32_t dbg) {
+    const uint32_t L = LT ? (uint32_t)LT : L_arg;
+    if (LT) {
+        // the cores are a function of L alone (sgc_api.cpp: A = [2, 2 + (L - 2) / 2), B = the rest of [2, L)); pass B is FINAL && !EXACT
+        constexpr uint32_t ca = LT ? ((uint32_t)LT - 2u) / 2u : 0u;
+        cv.cs = (FINAL && !EXACT) ? 2u + ca : 2u;
+        cv.cl = (FINAL && !EXACT) ? (uint32_t)LT - 2u - ca : ca;
+    }
     __shared__ uint64_t ent[SGC_CORE_EMAX];
     __shared__ uint32_t tgid[SGC_CORE_EMAX], cnt[SGC_CORE_EMAX];
     __shared__ uint16_t start[SGC_CORE_STARTS];
@@ -372,22 +383,26 @@ void sgc_launch_core(hipStream_t st, int pass, uint32_t L, const sgc_table_view 
     const ulonglong2 *am = reinterpret_cast<const ulonglong2 *>(amb);
     const sgc_runs ra = sgc_core_runs_a(g, ca, L, buf0, zeroed, small);
     const sgc_runs rb = make_runs(buf2, (char *)small + 2 * g.mat_a, g.mat_b, z + CP_MAXP, z + 2 * CP_MAXP + 1, KC_GRID, cb, L);
-    if (pass == 2)      // -x: the one exact-only pass over the runs k_count_slices left in buf0
-        hipLaunchKernelGGL((k_core<true, true>), dim3(KC_GRID), dim3(KC_THREADS), 0, st, ra, ca, am, L, lib, perm, (uint64_t *)nullptr, ra,
-                           counts, matched, dbg);
-    else if (pass == 0) // pass A: the runs k_count_slices left in buf0; forwards go to buf1 run by run, then to buf2 as pass B's runs
-        hipLaunchKernelGGL((k_core<false, false>), dim3(KC_GRID), dim3(KC_THREADS), 0, st, ra, ca, am, L, lib, perm, buf1, rb, counts, matched, dbg);
-    else                // pass B: what pass A forwarded
-        hipLaunchKernelGGL((k_core<true, false>), dim3(KC_GRID), dim3(KC_THREADS), 0, st, rb, cb, am, L, lib, perm, (uint64_t *)nullptr, rb,
-                           counts, matched, dbg);
+    // the specialisation for L = 20 needs the cores where it expects them (they are: sgc_set_library cuts them that way)
+    const bool l20 = L == 20 && ca.cs == 2 && ca.cl == 9 && cb.cs == 11 && cb.cl == 9;
+#define KC_LAUNCH(FINAL, EXACT, LT, IN, CV, FWD, OUT)                                                                        \
+    hipLaunchKernelGGL((k_core<FINAL, EXACT, LT>), dim3(KC_GRID), dim3(KC_THREADS), 0, st, IN, CV, am, L, lib, perm, FWD, OUT, counts, matched, dbg)
+    if (pass == 2) {    // -x: the one exact-only pass over the runs k_count_slices left in buf0
+        if (l20) KC_LAUNCH(true, true, 20, ra, ca, (uint64_t *)nullptr, ra); else KC_LAUNCH(true, true, 0, ra, ca, (uint64_t *)nullptr, ra);
+    } else if (pass == 0) { // pass A: the runs k_count_slices left in buf0; forwards go to buf1 run by run, then to buf2 as pass B's runs
+        if (l20) KC_LAUNCH(false, false, 20, ra, ca, buf1, rb); else KC_LAUNCH(false, false, 0, ra, ca, buf1, rb);
+    } else {            // pass B: what pass A forwarded
+        if (l20) KC_LAUNCH(true, false, 20, rb, cb, (uint64_t *)nullptr, rb); else KC_LAUNCH(true, false, 0, rb, cb, (uint64_t *)nullptr, rb);
+    }
+#undef KC_LAUNCH
 }
 
 // diagnostic (sgc_set_option "print_occupancy"): resident workgroups per CU as the runtime computes them
 void sgc_core_print_occupancy() {
     int a = -1, b = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_core<false, false>, KC_THREADS, 0);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_core<true, false>, KC_THREADS, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_core<false, false, 20>, KC_THREADS, 0);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_core<true, false, 20>, KC_THREADS, 0);
     hipFuncAttributes fa;
-    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_core<false, false>));
+    (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(k_core<false, false, 20>));
     fprintf(stderr, "occupancy (workgroups/CU): k_core<A> %d k_core<B> %d; k_core<A> lds %zu regs %d\n", a, b, fa.sharedSizeBytes, fa.numRegs);
 }
