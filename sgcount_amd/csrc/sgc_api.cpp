@@ -437,7 +437,7 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
     }
     if (!strcmp(key, "k1_wgs")) { c->k1_wgs = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 65536)); return SGC_OK; }
     if (!strcmp(key, "max_chunk")) {
-        if (value < 1 || value > (int64_t)0xF0000000ll) return fail(SGC_E_ARG, "max_chunk out of range");
+        if (value < 1 || value > (int64_t)(1ll << 28)) return fail(SGC_E_ARG, "max_chunk out of range (1 .. 2^28: the partition kernel addresses its pool with 32-bit byte offsets)");
         c->max_chunk = (uint64_t)value; return SGC_OK;
     }
     if (!strcmp(key, "align_slices")) { c->align_slices = value != 0; return SGC_OK; }       // takes effect at the next sgc_set_library

@@ -113,7 +113,11 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
     __shared__ uint64_t stage[PART_TILE];
     __shared__ uint8_t stage_p[PART_TILE];               // partition of every staged record
     __shared__ uint32_t cnt[PART_ARR], start[PART_ARR], blk[PART_ARR], fill[PART_ARR];
-    __shared__ uint32_t dst_a[PART_ARR], dst_b[PART_ARR], split[PART_ARR], nblk[PART_ARR];
+    __shared__ uint32_t nblk[PART_ARR];
+    // where a partition's run of the current tile goes, in one 16-byte word per partition (one LDS read per record in the
+    // write loop): x = first record of the run inside the staged tile, y = records that top up the open block, z = pool
+    // position of the first of those MINUS x, w = pool position of the first record of the new block(s) MINUS (x + y)
+    __shared__ uint4 runs[PART_ARR];
     __shared__ uint32_t next_free;
     const uint32_t P = 1u << (log2_slots - log2_slice), t = threadIdx.x;     // library slices; partition P = generic
     const uint32_t sh = 2 * (L + 2);
@@ -179,8 +183,7 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
                 if (c) {
                     const uint32_t room = PART_BLOCK - fill[q];          // 0 when no block is open
                     const uint32_t head = c < room ? c : room;
-                    split[q] = head;
-                    dst_a[q] = head ? blk[q] * PART_BLOCK + fill[q] : 0;
+                    uint4 rn = make_uint4(st0, head, (head ? blk[q] * PART_BLOCK + fill[q] : 0u) - st0, 0u);
                     fill[q] += head;
                     if (c > head) {
                         // the remainder goes to nb CONSECUTIVE new blocks (contiguous in the pool): all but the
@@ -195,9 +198,10 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
                         for (uint32_t i = 0; i < nb; i++) wl[i] = x + i;
                         nblk[q] += nb;
                         blk[q] = x + nb - 1;
-                        dst_b[q] = x * PART_BLOCK;
+                        rn.w = x * PART_BLOCK - (st0 + head);
                         fill[q] = rem - (nb - 1) * PART_BLOCK;
                     }
+                    runs[q] = rn;
                 }
             }
         }
@@ -215,15 +219,15 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
         for (uint32_t j = t; j < m; j += K1_THREADS) {
             const uint64_t r = stage[j];
             const uint32_t p = stage_p[j];
-            const uint32_t rank = j - start[p];
-            const uint64_t at = rank < split[p] ? (uint64_t)dst_a[p] + rank : (uint64_t)dst_b[p] + (rank - split[p]);
+            const uint4 rn = runs[p];
+            const uint32_t at = j + (j - rn.x < rn.y ? rn.z : rn.w);       // record index in the pool (< 2^29: byte offsets fit 32 bits)
+            char *pb = reinterpret_cast<char *>(pool);
             if (p6 && p != P) {
-                char *bb = reinterpret_cast<char *>(pool) + (at >> 10) * (PART_BLOCK * 8u);
-                const uint32_t idx = (uint32_t)at & (PART_BLOCK - 1u);
-                reinterpret_cast<uint32_t *>(bb)[idx] = (uint32_t)r;
-                reinterpret_cast<uint16_t *>(bb + P6_HI_OFF)[idx] = (uint16_t)(r >> 32);
+                const uint32_t bo = (at >> 10) << 13, idx = at & (PART_BLOCK - 1u);
+                *reinterpret_cast<uint32_t *>(pb + (size_t)(bo + (idx << 2))) = (uint32_t)r;
+                *reinterpret_cast<uint16_t *>(pb + (size_t)(bo + P6_HI_OFF + (idx << 1))) = (uint16_t)(r >> 32);
             } else {
-                pool[at] = r;
+                *reinterpret_cast<uint64_t *>(pb + (size_t)(at << 3)) = r;
             }
         }
         __syncthreads();
