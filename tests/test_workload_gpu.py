@@ -82,6 +82,36 @@ def test_synthetic_workload_vs_oracle_2m(env, exact):
     wl.close()
 
 
+@pytest.mark.parametrize("exact", [False, True])
+def test_every_fallback_mode_gives_the_same_table(env, exact):
+    """The shipped pass is a stack of results-preserving choices (six-byte slice blocks > direct miss runs > dense runs >
+    sub-partition tag > two-choice image > core-hashed slices); each one has a fallback that libraries of other shapes take
+    (L >= 22, slices that do not follow the core hash, ...).  Every rung of that ladder must count the same table — the
+    oracle's — on the same 1M reads."""
+    torch, S, synth, workload = env
+    n, ng = 1_000_000, 20_000
+    lib_text = None
+    want = None
+    ladder = [({}, {}), ({}, {"six_byte": 0}), ({}, {"direct": 0}), ({}, {"dense": 0}), ({}, {"tag_sub": 0}), ({}, {"cuckoo": 0}),
+              ({}, {"direct": 0, "cuckoo": 0, "tag_sub": 0}), ({"align_slices": 0}, {}), ({"align_slices": 0}, {"dense": 0, "cuckoo": 0}),
+              ({"rest_filter": 0}, {}), ({}, {"variant": 3}), ({}, {"variant": 1})]
+    for lib_opts, opts in ladder:
+        wl = workload.DeviceWorkload(n, ng, 20, one_mismatch=not exact, gen_chunk=500_000, lib_options=lib_opts)
+        for k, v in opts.items():
+            wl.dl.set_option(k, v)
+        wl.step()
+        counts, total, matched = wl.result()
+        if want is None:
+            lib_text = synth.library_fasta(wl.lib_seqs)
+            lib = O.Library(lib_text)
+            ctr = O.Counter(lib, None if exact else O.Permuter(lib), False, 30, 20, True)
+            for first in range(0, n, 500_000):
+                ctr.feed_text(synth.fastq_host(wl.lib_seqs, first, 500_000))
+            want = (ctr.table(), ctr.total_reads(), ctr.matched_reads())
+        assert (counts.tolist(), total, matched) == want, (lib_opts, opts)
+        wl.close()
+
+
 @pytest.mark.parametrize("variant,ng", [(4, 150_000), (3, 150_000), (4, 200_000)])
 def test_large_library_128_slices(env, variant, ng):
     """150k-200k guides need 128 library slices (64 hold ~105k) and, from ~170k, 512 core partitions: still the
