@@ -39,7 +39,13 @@
 #define K1_THREADS 1024u        // one 16-wave workgroup per CU: few workgroups leave few half-empty blocks open
 #endif
 #define PART_TILE (K1_THREADS * 8u) // records staged per tile in K1 (8 per lane)
-#define PART_BLOCK 1024u         // records per block (small blocks: fewer empty slots in the open blocks K1 leaves)
+#ifndef PART_LOG2_BLOCK
+#define PART_LOG2_BLOCK 9u
+#endif
+#define PART_BLOCK (1u << PART_LOG2_BLOCK) // records per block.  Every K1 workgroup leaves one part-filled block per partition: with
+                                 // 1024-record blocks a sixth of all slots of a 100M-read pass is empty, and k_count_slices pays for
+                                 // every block it walks, full or not (k1_wgs 256 instead of 512 halves the open blocks: K2 0.276 ->
+                                 // 0.243 ms, but K1 then runs one workgroup per CU); smaller blocks do the same without that price
 #define PART_MAXP 128u           // max library slices (~210k guides); partition index P_lib is the generic one
 #define PART_ARR (PART_MAXP + 1u)
 #define DESC_FILL_MASK 0xFFFFu
@@ -99,7 +105,7 @@ __device__ __forceinline__ uint32_t part_of(uint64_t rec, uint64_t kmask, uint32
 // block of 1024 clean records is 1024 x u32 (low words) followed by 1024 x u16 (bits 32..47) in the first 6 KiB of its
 // 8 KiB stride — a quarter less to write here and to read there, and both kernels run at what the memory system gives
 // this access pattern.  Blocks of the generic partition keep whole 8-byte records (their status does not fit).
-#define P6_HI_OFF 4096u
+#define P6_HI_OFF (PART_BLOCK * 4u)
 
 // ------------------------------------------------------------------------------------------------ K1
 template <int MODE>
@@ -223,7 +229,7 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
             const uint32_t at = j + (j - rn.x < rn.y ? rn.z : rn.w);       // record index in the pool (< 2^29: byte offsets fit 32 bits)
             char *pb = reinterpret_cast<char *>(pool);
             if (p6 && p != P) {
-                const uint32_t bo = (at >> 10) << 13, idx = at & (PART_BLOCK - 1u);
+                const uint32_t bo = (at >> PART_LOG2_BLOCK) << (PART_LOG2_BLOCK + 3u), idx = at & (PART_BLOCK - 1u);
                 *reinterpret_cast<uint32_t *>(pb + (size_t)(bo + (idx << 2))) = (uint32_t)r;
                 *reinterpret_cast<uint16_t *>(pb + (size_t)(bo + P6_HI_OFF + (idx << 1))) = (uint16_t)(r >> 32);
             } else {
@@ -283,16 +289,20 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                                                              const sgc_runs ep, const uint64_t *__restrict__ cuck,
                                                              uint64_t *__restrict__ mrun, uint32_t *__restrict__ mcur) {
     constexpr uint32_t S = 1u << LOG2_SLICE;
-    constexpr uint32_t RPT = PART_BLOCK / K2_THREADS;       // records per thread per block
-    constexpr uint32_t Q = K2_U * RPT;                       // records per thread per group
+    // A step of the workgroup takes BPS blocks side by side: lanes [h PART_BLOCK, (h + 1) PART_BLOCK) take record jl of the
+    // h-th of them (h is wave-uniform: a block is a whole number of waves); a group is K2_U steps.
+    static_assert(PART_BLOCK <= K2_THREADS && PART_BLOCK >= 64u, "a block is 1..16 waves of the workgroup");
+    constexpr uint32_t BPS = K2_THREADS / PART_BLOCK;        // blocks per step
+    constexpr uint32_t Q = K2_U;                             // records per thread per group
     __shared__ ulonglong2 tab[S / 2];                        // the slice, bucket by bucket
     __shared__ uint32_t cnt[S];
     __shared__ uint32_t list[K2_LIST];                       // block id << 11 | (fill - 1)
-    __shared__ uint32_t miss_cnt[2][K2_U], scratch[128], pre[K2_THREADS], wtmp[17];
+    __shared__ uint32_t miss_cnt[2][K2_U * BPS], scratch[128], pre[K2_THREADS], wtmp[17];
     __shared__ uint32_t hn[RUN_MAXP], rcur[RUN_MAXP], rbase, preg[K2_THREADS];   // epilogue: leftovers by partition of core pass A
     __shared__ uint32_t wmiss, mbase;                                              // DENSE: misses so far, start of the stretch in mrun
     __shared__ uint32_t wmiss4[4];                                                 // DIRECT: misses so far, by sub-partition
     const uint32_t t = threadIdx.x, p = blockIdx.x / G, g = blockIdx.x % G;
+    const uint32_t h = __builtin_amdgcn_readfirstlane(t / PART_BLOCK), jl = t % PART_BLOCK;
     const bool count_sub = ep.recs != nullptr && ep.sub_bits != 0xFFu;      // wave-uniform
     const uint32_t slice = lib.log2_slice < (uint32_t)LOG2_SLICE ? (1u << lib.log2_slice) : S;   // small libraries
     const uint32_t bmask = slice / 2 - 1u, gid_bits = lib.gid_bits;
@@ -309,7 +319,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     }
     for (uint32_t i = t; i < S; i += K2_THREADS) cnt[i] = 0;
     for (uint32_t i = t; i < RUN_MAXP; i += K2_THREADS) hn[i] = 0;
-    if (t < 2 * K2_U) miss_cnt[t / K2_U][t % K2_U] = 0;
+    if (t < 2 * K2_U * BPS) miss_cnt[t / (K2_U * BPS)][t % (K2_U * BPS)] = 0;
     // diagnostic stamps (SGC_STAMPS && (dbg & 512)): cycle counts of the phases of a few workgroups, printed at the end
     unsigned long long ts0 = 0, ts_scan = 0, ts_loop = 0;
     uint32_t n_groups_dbg = 0;
@@ -338,40 +348,35 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             list[i] = (b << 11) | ((desc[b] & DESC_FILL_MASK) - 1u);
         }
         __syncthreads();
-        if (SGC_STAMPS && (dbg & 512)) { ts_scan += __builtin_amdgcn_s_memtime() - ts0; ts0 = __builtin_amdgcn_s_memtime(); n_groups_dbg += (nl + K2_U - 1) / K2_U; }
+        if (SGC_STAMPS && (dbg & 512)) { ts_scan += __builtin_amdgcn_s_memtime() - ts0; ts0 = __builtin_amdgcn_s_memtime(); n_groups_dbg += (nl + K2_U * (K2_THREADS / PART_BLOCK) - 1) / (K2_U * (K2_THREADS / PART_BLOCK)); }
         // software pipeline over groups of K2_U blocks: `cur` is processed while `nxt` is in flight.  Block ids and
         // fills are wave-uniform (scalar registers).
         uint64_t cur[Q], nxt[Q];
         uint32_t ce[K2_U];                // list entries (block id << 11 | fill - 1; all ones = none), wave-uniform
+        // list entry of step s for this lane's block group (li counts steps, the list counts blocks)
+#define K2_ENTRY(s) __builtin_amdgcn_readfirstlane((s) * BPS + h < nl ? list[(s) * BPS + h] : 0xFFFFFFFFu)
+        const uint32_t nsteps = (nl + BPS - 1u) / BPS;
 #pragma unroll
         for (uint32_t u = 0; u < K2_U; u++) {
-            ce[u] = __builtin_amdgcn_readfirstlane(u < nl ? list[u] : 0xFFFFFFFFu);
-#pragma unroll
-            for (uint32_t k = 0; k < RPT; k++) {
-                const uint32_t j = k * K2_THREADS + t;
-                // lanes past the block's fill have nothing to read (one open block per K1 workgroup and slice is part empty)
-                cur[u * RPT + k] = (ce[u] != 0xFFFFFFFFu && j <= (ce[u] & 2047u)) ? k2_record<P6>(pool, ce[u] >> 11, j) : 0ull;
-            }
+            ce[u] = K2_ENTRY(u);
+            // lanes past the block's fill have nothing to read (one open block per K1 workgroup and slice is part empty)
+            cur[u] = (ce[u] != 0xFFFFFFFFu && jl <= (ce[u] & 2047u)) ? k2_record<P6>(pool, ce[u] >> 11, jl) : 0ull;
         }
-        for (uint32_t li = 0; li < nl; li += K2_U) {
+        for (uint32_t li = 0; li < nsteps; li += K2_U) {
             const uint32_t par = (li / K2_U) & 1u;
             // all records of group li are in registers (this also publishes the previous group's miss counts)
             if (!DENSE) __syncthreads();
-            if (!DENSE && t < K2_U) {
+            if (!DENSE && t < K2_U * BPS) {
                 if (li) {
-                    const uint32_t e = list[li - K2_U + t];
+                    const uint32_t e = (li - K2_U) * BPS + t < nl ? list[(li - K2_U) * BPS + t] : 0xFFFFFFFFu;
                     if (e != 0xFFFFFFFFu) desc[e >> 11] = ((p + 1) << 16) | miss_cnt[par ^ 1u][t];
                 }
                 miss_cnt[par ^ 1u][t] = 0;
             }
 #pragma unroll
             for (uint32_t u = 0; u < K2_U; u++) {
-                const uint32_t ne = __builtin_amdgcn_readfirstlane(li + K2_U + u < nl ? list[li + K2_U + u] : 0xFFFFFFFFu);
-#pragma unroll
-                for (uint32_t k = 0; k < RPT; k++) {
-                    const uint32_t j = k * K2_THREADS + t;
-                    nxt[u * RPT + k] = (ne != 0xFFFFFFFFu && j <= (ne & 2047u)) ? k2_record<P6>(pool, ne >> 11, j) : 0ull;
-                }
+                const uint32_t ne = K2_ENTRY(li + K2_U + u);
+                nxt[u] = (ne != 0xFFFFFFFFu && jl <= (ne & 2047u)) ? k2_record<P6>(pool, ne >> 11, jl) : 0ull;
             }
             // Centered-exact probe (src/counter.rs:111) of the Q records against the slice in LDS.  The LDS copy
             // holds bare keys, so a bucket resolves with four 64-bit compares and no branches (K2 is bound by
@@ -381,8 +386,8 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             for (uint32_t q = 0; q < Q; q++) {
                 // K1 sends every record with a non-zero status to the generic partition, so a slice partition
                 // only holds clean records: no status test here
-                const uint32_t u = q / RPT, j = (q % RPT) * K2_THREADS + t;
-                const bool valid = ce[u] != 0xFFFFFFFFu && j <= (ce[u] & 2047u);
+                const uint32_t u = q;
+                const bool valid = ce[u] != 0xFFFFFFFFu && jl <= (ce[u] & 2047u);
                 const uint64_t key = (cur[q] >> 2) & kmask;
                 // home slot inside the slice: left there by k_partition, or (six-byte records) hashed again here
                 const uint32_t s1 = P6 ? sgc_hash32(key) >> (32u - ls) : (uint32_t)(cur[q] >> PART_TAG_SHIFT);
@@ -424,22 +429,22 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                     const uint32_t pos = atomicAdd(mv ? &wmiss : &scratch[64u + (t & 63u)], 1u);
                     if (mv) mrun[(uint64_t)run0 + pos] = cur[q] & PART_TAG_MASK;
                 } else {
-                    const uint32_t pos = atomicAdd(mv ? &miss_cnt[par][u] : &scratch[64u + (t & 63u)], 1u);
+                    const uint32_t pos = atomicAdd(mv ? &miss_cnt[par][u * BPS + h] : &scratch[64u + (t & 63u)], 1u);
                     if (mv) pool[(uint64_t)(ce[u] >> 11) * PART_BLOCK + ((part_front(ce[u] >> 11) + pos) & (PART_BLOCK - 1u))] = cur[q] & PART_TAG_MASK;
                 }
             }
 #pragma unroll
             for (uint32_t q = 0; q < Q; q++) cur[q] = nxt[q];
 #pragma unroll
-            for (uint32_t u = 0; u < K2_U; u++)
-                ce[u] = __builtin_amdgcn_readfirstlane(li + K2_U + u < nl ? list[li + K2_U + u] : 0xFFFFFFFFu);
+            for (uint32_t u = 0; u < K2_U; u++) ce[u] = K2_ENTRY(li + K2_U + u);
         }
+#undef K2_ENTRY
         __syncthreads();
         if (nl && !DENSE) {
-            const uint32_t last = ((nl - 1) / K2_U) * K2_U, par = (last / K2_U) & 1u;
-            if (t < K2_U) {
-                if (last + t < nl) {
-                    const uint32_t e = list[last + t];
+            const uint32_t last = ((nsteps - 1) / K2_U) * K2_U, par = (last / K2_U) & 1u;
+            if (t < K2_U * BPS) {
+                if (last * BPS + t < nl) {
+                    const uint32_t e = list[last * BPS + t];
                     if (e != 0xFFFFFFFFu) desc[e >> 11] = ((p + 1) << 16) | miss_cnt[par][t];
                 }
                 miss_cnt[par][t] = 0;
