@@ -5,6 +5,7 @@
 // the count path: without a HIP device sgc_init() fails and the caller must surface that.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -453,7 +454,11 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
         if (value < 1 || value > 64) return fail(SGC_E_ARG, "perm_bloom_bits must be 1..64");
         c->perm_bloom_bits = (uint32_t)value; return SGC_OK;
     }
-    if (!strcmp(key, "print_occupancy")) { sgc_core_print_occupancy(); return SGC_OK; }
+    if (!strcmp(key, "print_occupancy")) {
+        sgc_core_print_occupancy();
+        fprintf(stderr, "scratch: pool %p (%zu MB) runs %p (%zu MB) desc %p\n", c->d_pool, c->pool_cap >> 20, c->d_cbuf, c->cbuf_cap >> 20, c->d_desc);
+        return SGC_OK;
+    }
     if (!strcmp(key, "per_lane")) {
         if (value != 1 && value != 2 && value != 4) return fail(SGC_E_ARG, "per_lane must be 1, 2 or 4");
         c->per_lane = (int)value; return SGC_OK;

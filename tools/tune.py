@@ -73,6 +73,7 @@ def main():
             res[v]["part"].append(t.part_ms / args.steps)
             res[v]["miss"].append(t.miss_ms / args.steps)
             res[v]["wall"].append(e0.elapsed_time(e1) / args.steps)
+    wl.dl.set_option("print_occupancy", 1)         # where the scratch buffers fell (stderr)
     assert args.nocheck or len(set(sig.values())) == 1, "variants disagree: %r" % sig
     print("reads=%d workload=%s table=%s" % (args.reads, args.workload, next(iter(sig.values()))))
     for v in variants:
