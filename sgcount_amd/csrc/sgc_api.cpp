@@ -50,7 +50,7 @@ struct sgc_ctx {
     // whether K1 and K2 run in their fast or their slow regime (~10 % apart), so the first large pass tries a few placements
     // and keeps the fastest
     bool verbose = false;              // diagnostics on stderr (option "verbose")
-    int place_trials = 8;              // allocations tried (1 = take what hipMalloc gives)
+    int place_trials = 16;             // allocations tried (1 = take what hipMalloc gives)
     void *placed_pool = nullptr, *placed_cbuf = nullptr;     // the buffers the trials chose (re-run if they were re-allocated since)
     void *d_dummy = nullptr; size_t dummy_cap = 0;           // counts of the trial passes go nowhere
     bool six_byte = true;              // ... and the slice blocks hold six-byte records (needs direct, L <= 21)
@@ -259,6 +259,8 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
                         }
                         ok = ok && hipEventRecord(e1, c->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
                              hipEventElapsedTime(&cd.ms, e0, e1) == hipSuccess;
+                        // the regimes are ~10 % apart: a candidate that far ahead of the first one is the fast one — stop looking
+                        if (ok && k && cd.ms < 0.92f * cands[0].ms) break;
                     }
                     if (e0) hipEventDestroy(e0);
                     if (e1) hipEventDestroy(e1);
