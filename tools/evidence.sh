@@ -1,7 +1,8 @@
 #!/bin/bash
 # usage (on the GPU box, through gpurun): tools/evidence.sh <round-dir>      e.g. tools/evidence.sh r02
 # Collects everything DESIGN.md §6 cites into gpurun_out/<round-dir>/ (copy it to profiles/<round-dir>/ afterwards):
-#   kernel_stats_{1mm,exact}.csv   rocprofv3 --kernel-trace --stats of `bench.py --steps 10` (count pipeline)
+#   kernel_stats_{1mm,exact}.csv   rocprofv3 --kernel-trace --stats of `bench.py --steps 10` (count pipeline; all dispatches, the placement
+#                                  trials' included) + kernel_stats_timed_*.csv: the last 10 dispatches of every kernel = the timed region
 #   kernel_stats_ingest.csv        the same of tools/tune_ingest.py on 10M reads (FASTQ ingest kernels) + ingest.txt (TB/s of text)
 #   pmc_traffic.json               HBM bytes per pass from separate --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py)
 #   sq_*.txt                       SQ counters of the count kernels (tools/pmc_table.py), one --pmc pass per group
@@ -12,6 +13,7 @@ BENCH="--steps 10 --warmup 2 --cpu-seconds 0 --e2e-reads 0"
 for W in 1mm exact; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $D/prof_$W -- python3 $R/bench.py $BENCH --workload $W > $D/bench_prof_$W.log 2>&1 || exit 1
   cp $(ls -t $D/prof_$W/*/*kernel_stats.csv | head -1) $D/kernel_stats_$W.csv
+  python3 $R/tools/trace_timed.py $(ls -t $D/prof_$W/*/*kernel_trace.csv | head -1) 10 > $D/kernel_stats_timed_$W.csv
   grep '^{' $D/bench_prof_$W.log > $D/bench_under_rocprof_$W.json
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $D/prof_ingest -- python3 $R/tools/tune_ingest.py --reads 10000000 > $D/ingest_prof.log 2>&1 || exit 1

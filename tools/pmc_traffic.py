@@ -23,12 +23,17 @@ PIPE = ("k_partition", "k_count_slices", "k_cp_count", "k_cp_scatter", "k_core",
 def per_kernel(d, counter):
     f = max(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)
     acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] != counter:
-            continue
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r.get("Dispatch_Id", 0)))
+    for r in rows:
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
         acc[name].append(float(r["Counter_Value"]))
-    steps = len(acc["k_partition"])                               # one k_partition launch per step
+    steps = len(acc["k_export"])                                  # one k_export launch per step
+    # k_partition / k_count_slices also run in the placement trials of the first pass (before any k_core): only their last
+    # `steps` dispatches belong to steps
+    for k in ("k_partition", "k_count_slices"):
+        if k in acc:
+            acc[k] = acc[k][-steps:]
     return {k: sum(v) / steps for k, v in acc.items()}            # per step (a kernel may run twice in a step)
 
 
