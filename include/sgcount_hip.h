@@ -188,12 +188,11 @@ void sgc_free_pinned(void *p);
 /* Tuning knobs (all results-preserving): "variant" (count path variant 0..4; default 4), "max_chunk"
  * (records per internal pass), "k1_wgs" (workgroups of the partition kernel), "per_lane" (variant 2), "host_build" /
  * "perm_bloom_bits" (how the next sgc_set_library builds the single-mismatch table and its filter), "force_bytes" (the next
- * sgc_set_library uses the byte-string path even for a library the packed path could serve), "place_trials" (1..16, default 16:
- * where the scratch buffers of a large pass — 32M records or more — fall in device memory decides whether its partition and
- * slice-count kernels run ~10 % faster or slower, so the first such pass allocates up to that many candidates, times the two kernels
- * on each (a few ms each, all held at once: up to 6 GB per candidate for 100M records; it stops at the first candidate 8 % ahead of the
- * first one, or when memory runs short) and keeps the fastest; 1 = take what
- * hipMalloc gives), "verbose" (diagnostics on stderr).  No environment
+ * sgc_set_library uses the byte-string path even for a library the packed path could serve), "place_trials" (1..64, default 32:
+ * where the block pool of a large pass — 32M records or more — falls in device memory decides whether its partition and
+ * slice-count kernels run ~10 % faster or slower, so the first such pass allocates up to that many candidate pools (all held at once:
+ * ~1 GB each for 100M records), times the partition kernel on each (under 1 ms each; it stops at a candidate 11 % ahead of the slowest
+ * seen, or when memory runs short) and keeps the fastest; 1 = take what hipMalloc gives), "verbose" (diagnostics on stderr).  No environment
  * variable changes what the library computes or which kernels it runs.  "dbg" sets
  * timing-only ablation flags of the kernels — results are WRONG while it is non-zero, so it is refused unless
  * SGC_ALLOW_DBG=1 is in the environment (tools/tune.py sets it). */

@@ -46,13 +46,11 @@ struct sgc_ctx {
     uint64_t *d_lib_slots = nullptr, *d_perm_slots = nullptr, *d_lib_cuckoo = nullptr;
     bool dense = true;                 // k_count_slices writes its misses as dense runs (no per-group barrier) instead of in place
     bool direct = true;                // ... one run per partition of core pass A, consumed where it lies (needs dense + tag_sub)
-    // Placement trials (DESIGN.md §6 "the two regimes of the pass"): where the pool and the run buffers fall in memory decides
-    // whether K1 and K2 run in their fast or their slow regime (~10 % apart), so the first large pass tries a few placements
-    // and keeps the fastest
+    // Placement trials (DESIGN.md §6 "the two regimes of the pass"): where the pool falls in memory decides whether K1 and K2
+    // run in their fast or their slow regime (~10 % apart), so the first large pass tries a few placements and keeps the fastest
     bool verbose = false;              // diagnostics on stderr (option "verbose")
-    int place_trials = 16;             // allocations tried (1 = take what hipMalloc gives)
-    void *placed_pool = nullptr, *placed_cbuf = nullptr;     // the buffers the trials chose (re-run if they were re-allocated since)
-    void *d_dummy = nullptr; size_t dummy_cap = 0;           // counts of the trial passes go nowhere
+    int place_trials = 32;             // allocations tried (1 = take what hipMalloc gives)
+    void *placed_pool = nullptr;       // the pool the trials chose (they run again if it was re-allocated since)
     bool six_byte = true;              // ... and the slice blocks hold six-byte records (needs direct, L <= 21)
     bool tag_sub = true;               // K1 tags the pass-A partition inside the slice, K2 counts misses by it (no histogram sweep)
     bool use_cuckoo = true;            // k_count_slices probes the two-choice image of the slices (no chain loop)
@@ -224,43 +222,34 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
                 if (rc) return rc;
                 rc = ensure(&c->d_csmall, &c->csmall_cap, cg.small_bytes);
                 if (rc) return rc;
-                if (direct && c->place_trials > 1 && chunk >= (1ull << 25) && (c->placed_pool != c->d_pool || c->placed_cbuf != c->d_cbuf)) {
-                    // placement trials: K1 + K2 of this very chunk (counts into a dummy vector), twice per candidate, the second
-                    // run timed; all candidates stay allocated during the search so that every one falls somewhere else
-                    rc = ensure(&c->d_dummy, &c->dummy_cap, (size_t)c->n * 4 + 64);
-                    if (rc) return rc;
-                    struct cand { void *pool, *cbuf; float ms; };
+                if (direct && c->place_trials > 1 && chunk >= (1ull << 25) && c->placed_pool != c->d_pool) {
+                    // Placement trials.  K1 and K2 speed up and slow down TOGETHER from candidate to candidate (K1 0.30 ... 0.36 ms,
+                    // K2 0.24 ... 0.31), and K1 touches nothing of ours but the pool: it is the pool's place in memory that decides.
+                    // So: up to place_trials pool allocations — all held during the search, so that each falls somewhere else —,
+                    // K1 of this very chunk twice on each, the second run timed; the fastest is kept.
+                    struct cand { void *pool; float ms; };
                     std::vector<cand> cands;
-                    cands.push_back({c->d_pool, c->d_cbuf, 0.f});
+                    cands.push_back({c->d_pool, 0.f});
                     hipEvent_t e0 = nullptr, e1 = nullptr;
                     bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+                    float worst = 0.f;
                     for (int k = 0; ok && k < c->place_trials; k++) {
                         if (k) {
-                            void *P = nullptr, *C = nullptr;
-                            if (hipMalloc(&P, c->pool_cap) != hipSuccess || hipMalloc(&C, c->cbuf_cap) != hipSuccess) {
-                                if (P) hipFree(P);
-                                (void)hipGetLastError();
-                                break;                                    // out of memory: settle for what there is
-                            }
-                            cands.push_back({P, C, 0.f});
+                            void *P = nullptr;
+                            if (hipMalloc(&P, c->pool_cap) != hipSuccess) { (void)hipGetLastError(); break; }    // out of memory: settle for what there is
+                            cands.push_back({P, 0.f});
                         }
                         cand &cd = cands.back();
-                        uint64_t *tp = (uint64_t *)cd.pool, *tb0 = (uint64_t *)cd.cbuf;
-                        uint64_t *tm = (uint64_t *)((char *)cd.cbuf + cg.runs_a_bytes);
-                        void *zeroed = (char *)c->d_desc + g.desc_tail_off;
-                        sgc_runs tra = sgc_core_runs_a(cg, c->v_core[0], c->L, tb0, zeroed, c->d_csmall);
-                        tra.sub_bits = (uint32_t)sub;
-                        uint32_t *tcur = (uint32_t *)zeroed + 2 * RUN_MAXP + 2;
                         for (int rep = 0; rep < 2; rep++) {
                             if (rep) ok = ok && hipEventRecord(e0, c->stream) == hipSuccess;
-                            sgc_launch_part_k1(c->stream, p, chunk, c->L, c->v_lib, (uint32_t)sub, g, tp, desc, six);
-                            sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, tp, desc, (uint32_t *)c->d_dummy, (unsigned long long *)((char *)c->d_dummy + (((size_t)c->n * 4 + 15) & ~(size_t)7)),
-                                               0u, &tra, c->use_cuckoo ? c->d_lib_cuckoo : nullptr, tm, tcur, true, six);
+                            sgc_launch_part_k1(c->stream, p, chunk, c->L, c->v_lib, (uint32_t)sub, g, (uint64_t *)cd.pool, desc, six);
                         }
                         ok = ok && hipEventRecord(e1, c->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
                              hipEventElapsedTime(&cd.ms, e0, e1) == hipSuccess;
-                        // the regimes are ~10 % apart: a candidate that far ahead of the first one is the fast one — stop looking
-                        if (ok && k && cd.ms < 0.92f * cands[0].ms) break;
+                        if (c->verbose) fprintf(stderr, "placement trial %d: pool %p: K1 %.3f ms\n", k, cd.pool, cd.ms);
+                        worst = std::max(worst, cd.ms);
+                        // the regimes are >= 10 % apart: a candidate that far ahead of the slowest one seen is in the fast one
+                        if (ok && k >= 3 && cd.ms < 0.89f * worst) break;
                     }
                     if (e0) hipEventDestroy(e0);
                     if (e1) hipEventDestroy(e1);
@@ -268,16 +257,13 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
                     size_t best = 0;
                     for (size_t k = 1; k < cands.size(); k++)
                         if (ok && cands[k].ms > 0.f && cands[k].ms < cands[best].ms) best = k;
-                    if (c->verbose)
-                        for (size_t k = 0; k < cands.size(); k++)
-                            fprintf(stderr, "placement trial %zu: pool %p runs %p: K1 + K2 %.3f ms%s\n", k, cands[k].pool, cands[k].cbuf, cands[k].ms, k == best ? "  <- kept" : "");
                     for (size_t k = 0; k < cands.size(); k++)
-                        if (k != best) { hipFree(cands[k].pool); hipFree(cands[k].cbuf); }
-                    c->d_pool = cands[best].pool; c->d_cbuf = cands[best].cbuf;
-                    c->placed_pool = c->d_pool; c->placed_cbuf = c->d_cbuf;
+                        if (k != best) hipFree(cands[k].pool);
+                    c->d_pool = cands[best].pool;
+                    c->placed_pool = c->d_pool;
                     pool = (uint64_t *)c->d_pool;
                     HIP_TRY(hipGetLastError());
-                    // the real pass starts over on the chosen buffers
+                    // the real pass starts over on the chosen pool
                     { timed t(c, T_PART); sgc_launch_part_k1(c->stream, p, chunk, c->L, c->v_lib, tag_sub ? (uint32_t)sub : 0u, g, pool, desc, six); }
                 }
                 uint64_t *buf0 = (uint64_t *)c->d_cbuf, *mrun = c->dense ? (uint64_t *)((char *)c->d_cbuf + cg.runs_a_bytes) : nullptr;
@@ -460,7 +446,6 @@ void sgc_free(sgc_ctx *c) {
     if (c->d_recs) hipFree(c->d_recs);
     if (c->d_gids) hipFree(c->d_gids);
     if (c->d_pool) hipFree(c->d_pool);
-    if (c->d_dummy) hipFree(c->d_dummy);
     if (c->d_desc) hipFree(c->d_desc);
     if (c->d_cbuf) hipFree(c->d_cbuf);
     if (c->d_csmall) hipFree(c->d_csmall);
@@ -520,8 +505,8 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
     }
     if (!strcmp(key, "verbose")) { c->verbose = value != 0; return SGC_OK; }
     if (!strcmp(key, "place_trials")) {
-        if (value < 1 || value > 16) return fail(SGC_E_ARG, "place_trials must be 1..16");
-        c->place_trials = (int)value; c->placed_pool = c->placed_cbuf = nullptr;
+        if (value < 1 || value > 64) return fail(SGC_E_ARG, "place_trials must be 1..64");
+        c->place_trials = (int)value; c->placed_pool = nullptr;
         return SGC_OK;
     }
     if (!strcmp(key, "print_occupancy")) {
