@@ -168,12 +168,18 @@ def _mem_available():
 
 
 def _run_cli(cli, argv, stats=None):
-    t0 = time.perf_counter()
+    t0, u0 = time.perf_counter(), time.time()
     p = subprocess.run([cli] + argv + (["--stats-json", stats] if stats else []), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    dt = time.perf_counter() - t0
+    dt, u1 = time.perf_counter() - t0, time.time()
     if p.returncode != 0:
         raise RuntimeError("sgcount-hip failed (%d): %s" % (p.returncode, p.stderr.decode()[-400:]))
-    return dt, (json.load(open(stats)) if stats else None)
+    st = json.load(open(stats)) if stats else None
+    if st and "count_entered_unix_s" in st:
+        # what the stage timers inside count() do not see: exec + dynamic linking + argument handling before it, and
+        # the teardown (device contexts, pinned buffers, process exit) after the table is written
+        st["process_start_to_count_s"] = st["count_entered_unix_s"] - u0
+        st["teardown_s"] = u1 - st["stats_written_unix_s"]
+    return dt, st
 
 
 def _table_counts(path, n_guides):
@@ -185,6 +191,24 @@ def _table_counts(path, n_guides):
             g, c = line.split(b"\t")
             counts[int(g[2:])] = int(c)
     return counts
+
+
+def write_fastq(wl, n, path, chunk=2_000_000):
+    """The first n reads of the workload's sample as FASTQ text (generated on the device, written through a pinned buffer)."""
+    import torch
+    from sgcount_amd import synth
+    pinned = None
+    with open(path, "wb", buffering=0) as f:
+        for first in range(0, n, chunk):
+            m = min(chunk, n - first)
+            text, _ = synth.fastq_device(wl.lib_dev, first, m, wl.reads_seed, wl.mode)
+            if pinned is None or pinned.numel() < text.numel():
+                pinned = torch.empty(int(text.numel() * 1.05), dtype=torch.uint8, pin_memory=True)
+            pinned[: text.numel()].copy_(text)
+            torch.cuda.synchronize()
+            f.write(memoryview(pinned.numpy())[: text.numel()])
+            del text
+    del pinned
 
 
 def e2e_block(wl, args, exact, cpu):
@@ -216,44 +240,52 @@ def e2e_block(wl, args, exact, cpu):
         open(lib_path, "wb").write(synth.library_fasta(wl.lib_seqs))
         t0 = time.perf_counter()
         chunk = 2_000_000
-        pinned = None
-        with open(fq, "wb", buffering=0) as f:
-            for first in range(0, n, chunk):
-                m = min(chunk, n - first)
-                text, _ = synth.fastq_device(wl.lib_dev, first, m, wl.reads_seed, wl.mode)
-                if pinned is None or pinned.numel() < text.numel():
-                    pinned = torch.empty(int(text.numel() * 1.05), dtype=torch.uint8, pin_memory=True)
-                pinned[: text.numel()].copy_(text)
-                torch.cuda.synchronize()
-                f.write(memoryview(pinned.numpy())[: text.numel()])
-                del text
-        del pinned
+        write_fastq(wl, n, fq, chunk)
         size = os.path.getsize(fq)
         out["fastq"] = {"reads": n, "bytes": size, "dir": where, "write_s": time.perf_counter() - t0}
         cli = hostlib.cli_path()
         base = ["-l", lib_path, "-a", "30", "-q", "-o", table] + (["-x"] if exact else [])
-        # plain text: two untimed-stats runs (best of), then one with the stage timers on
-        walls = [_run_cli(cli, base + ["-i", fq])[0] for _ in range(2)]
+        # plain text: three runs, every one with the stage timers on.  The FIRST run of a fresh box is reported on its own
+        # (wall_s_first_run): it is the run a user makes, and it pays for whatever is cold (shared libraries of the ROCm
+        # runtime paged in from the image, first use of the device by a new process); wall_s is the best of the later runs.
+        def stages_of(stats):
+            smp = stats["samples"][0]
+            return {"process_start_to_count_s": stats.get("process_start_to_count_s"), "library_load_s": stats["library_load_s"],
+                    "device_init_s": stats.get("device_init_s"), "table_build_s": stats["table_build_s"],
+                    "sample_s": smp["wall_s"], "table_write_s": stats["table_write_s"], "context_free_s": stats.get("context_free_s"),
+                    "process_exit_s": stats.get("teardown_s"),
+                    "feeder_setup_s": smp.get("feeder_setup_s"), "first_push_s": smp.get("first_push_s"),
+                    "path": "host scan -> packed records" if smp.get("scan_path") else ("FASTQ text parsed on the GPU" if smp.get("text_path") else "record reader"),
+                    "host_copy_s": smp.get("host_copy_s"),
+                    "file_read_busy_s_sum_over_threads": smp["read_busy_s"], "reader_threads": smp["reader_threads"],
+                    "host_waited_for_text_s": smp["wait_for_text_s"], "host_waited_for_upload_s": smp["wait_for_upload_s"],
+                    "host_in_push_calls_s": smp["push_s"], "drain_s": smp["finish_s"],
+                    "h2d_s": smp["h2d_ms"] / 1e3, "ingest_kernels_s": smp["ingest_kernels_ms"] / 1e3,
+                    "count_kernels_s": smp["count_kernels_ms"] / 1e3}
+        runs = [_run_cli(cli, base + ["-i", fq], stats=os.path.join(d, "stats%d.json" % k)) for k in range(3)]
         got = _table_counts(table, args.guides)
         wl.step(0, n)
         want, total, matched = wl.result()
         parity = bool(np.array_equal(got, want))
-        _, stats = _run_cli(cli, base + ["-i", fq], stats=os.path.join(d, "stats.json"))
+        walls = [r[0] for r in runs]
+        best = min(range(1, len(runs)), key=lambda k: walls[k])
+        wall, stats = walls[best], runs[best][1]
         smp = stats["samples"][0]
-        wall = min(walls)
         out["plain"] = {
             "wall_s": wall, "reads_per_s": n / wall, "text_GBps": size / wall / 1e9, "wall_s_all_runs": walls,
+            "wall_s_first_run": walls[0], "reads_per_s_first_run": n / walls[0],
             "table_equals_resident_pass": parity,
-            "stages": {"library_load_s": stats["library_load_s"], "table_build_s": stats["table_build_s"],
-                       "sample_s": smp["wall_s"], "table_write_s": stats["table_write_s"],
-                       "file_read_busy_s_sum_over_threads": smp["read_busy_s"], "reader_threads": smp["reader_threads"],
-                       "host_waited_for_text_s": smp["wait_for_text_s"], "host_waited_for_upload_s": smp["wait_for_upload_s"],
-                       "host_in_push_calls_s": smp["push_s"], "drain_s": smp["finish_s"],
-                       "h2d_s": smp["h2d_ms"] / 1e3, "ingest_kernels_s": smp["ingest_kernels_ms"] / 1e3,
-                       "count_kernels_s": smp["count_kernels_ms"] / 1e3,
-                       "note": "stage timers from a separate run with --stats-json (HIP events on); uploads, ingest and "
-                               "count kernels of consecutive parts overlap, so the stages do not add up to sample_s"},
-            "ingest_text_GBps_vs_hbm": {"achieved": size / max(smp["ingest_kernels_ms"], 1e-9) / 1e6, "peak": HBM_PEAK_GBPS,
+            "stages": dict(stages_of(stats), note="stage timers of the best later run (HIP events on in every run); uploads, ingest "
+                           "and count kernels of consecutive parts overlap, so the stages do not add up to sample_s"),
+            "stages_first_run": stages_of(runs[0][1]),
+        }
+        # the validated fallback (and the path of .gz / BGZF input): the text itself goes over PCIe and the GPU parses it
+        wall_t, stats_t = _run_cli(cli, base + ["-i", fq, "--pack", "fastq"], stats=os.path.join(d, "stats_text.json"))
+        smp_t = stats_t["samples"][0]
+        out["plain_gpu_parsed_text"] = {
+            "wall_s": wall_t, "reads_per_s": n / wall_t, "table_equals_resident_pass": bool(np.array_equal(_table_counts(table, args.guides), want)),
+            "stages": stages_of(stats_t),
+            "ingest_text_GBps_vs_hbm": {"achieved": size / max(smp_t["ingest_kernels_ms"], 1e-9) / 1e6, "peak": HBM_PEAK_GBPS,
                                          "note": "FASTQ text bytes / Σ(k_fastq_count + k_scan_tiles + k_fastq_pack) time"},
         }
         if cpu:
@@ -261,8 +293,11 @@ def e2e_block(wl, args, exact, cpu):
             out["cpu_port"] = {"reads_per_s_setup_excluded": rate, "reads_per_s_setup_included": n / (n / rate + setup),
                                "setup_s": setup, "cores": 1,
                                "note": "the oracle's measured FASTQ-text rate (cpu_baseline) projected to the e2e sample size"}
+            inc = out["cpu_port"]["reads_per_s_setup_included"]
             out["speedup_plain"] = {"vs_cpu_setup_excluded": out["plain"]["reads_per_s"] / rate,
-                                    "vs_cpu_setup_included": out["plain"]["reads_per_s"] / out["cpu_port"]["reads_per_s_setup_included"]}
+                                    "vs_cpu_setup_included": out["plain"]["reads_per_s"] / inc,
+                                    "first_run_vs_cpu_setup_excluded": out["plain"]["reads_per_s_first_run"] / rate,
+                                    "first_run_vs_cpu_setup_included": out["plain"]["reads_per_s_first_run"] / inc}
         # .gz: one deflate stream is sequential — the run is bound by a single inflating core, whatever the GPU does
         ngz = min(args.e2e_gz_reads, n)
         if ngz > 0:

@@ -136,6 +136,17 @@ int sgc_sample_begin(sgc_ctx *, sgc_sample **out, int reverse, uint32_t offset, 
  * ctx stream; a host buffer may be reused after sgc_sample_sync(). */
 int sgc_sample_push_packed(sgc_sample *, const void *records, uint64_t n, int where);
 
+/* Streaming form for a host that packs the records itself (the north star's split: the host streams FASTQ, 2-bit-packs
+ * the reads and ships pinned batches; replaces the iterator of Counter::count, src/counter.rs:211-236, with
+ * sgc_pack_reads_host / the scanner of the C++ host in the role of Counter::apply_trim).  `records` is HOST memory (pinned:
+ * the copy is then truly asynchronous).  The records are uploaded on the ctx's upload stream into a device-side batch
+ * buffer of the sample; a count pass runs whenever a batch ("batch_records" option, default 2^24) is full and at the next
+ * sgc_sample_flush / _finish / _sync / _export_device, so that many small pushes cost one pass — each pass has a fixed cost
+ * of a few launches and table stagings.  Two batch buffers alternate: the upload of one batch overlaps the count pass of the
+ * batch before.  The host buffer may be reused once sgc_sample_wait_uploads says so.  Not to be interleaved on one ctx with
+ * the asynchronous pushes of another sample. */
+int sgc_sample_push_packed_async(sgc_sample *, const void *records, uint64_t n);
+
 /* Same, from raw read bytes: the device packs (pack kernel) then counts. */
 int sgc_sample_push_reads(sgc_sample *, const uint8_t *seqs, const uint64_t *offsets, uint64_t n, int where);
 
@@ -157,8 +168,8 @@ int sgc_sample_push_fastq(sgc_sample *, const uint8_t *text, uint64_t n_bytes, i
 int sgc_sample_push_fastq_part(sgc_sample *, const uint8_t *text, uint64_t n_bytes, int where, uint64_t first_line,
                                uint64_t n_newlines, uint64_t *n_records_out);
 
-/* Blocks until at most max_pending of the most recent host-text uploads are still in flight: the host buffers of
- * all earlier sgc_sample_push_fastq_part calls can then be overwritten. */
+/* Blocks until at most max_pending of the most recent asynchronous uploads (sgc_sample_push_fastq_part with host text,
+ * sgc_sample_push_packed_async) are still in flight: the host buffers of all earlier ones can then be overwritten. */
 int sgc_sample_wait_uploads(sgc_sample *, uint32_t max_pending);
 
 int sgc_sample_sync(sgc_sample *);

@@ -45,6 +45,7 @@ SYMBOLS = {
     "sgc_pack_reads_device": (_i, [_vp, _vp, _vp, _u64, _i, _u32, _i, _vp]),
     "sgc_sample_begin": (_i, [_vp, C.POINTER(_vp), _i, _u32, _i]),
     "sgc_sample_push_packed": (_i, [_vp, _vp, _u64, _i]),
+    "sgc_sample_push_packed_async": (_i, [_vp, _vp, _u64]),
     "sgc_sample_push_reads": (_i, [_vp, _u8p, _vp, _u64, _i]),
     "sgc_sample_push_fastq": (_i, [_vp, _u8p, _u64, _i, C.POINTER(_u64)]),
     "sgc_sample_push_fastq_part": (_i, [_vp, _u8p, _u64, _i, _u64, _u64, C.POINTER(_u64)]),

@@ -370,6 +370,9 @@ size_t count_newlines(const uint8_t *p, size_t n) {
 static double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+static double unix_s() {
+    return std::chrono::duration<double>(std::chrono::system_clock::now().time_since_epoch()).count();
+}
 
 TextFeeder::TextFeeder(const std::string &path_, size_t slice_bytes, size_t ring, size_t threads, void *(*alloc)(size_t),
                        void (*release)(void *), size_t inflate_threads)
@@ -651,9 +654,12 @@ void TextFeeder::release_below(size_t k) {
 // Streams one FASTQ file through sgc_sample_push_fastq_part.  Returns false (nothing pushed) if the input is not
 // FASTQ (first byte not '@'): the caller then uses the record reader.
 static bool count_fastq_text(sgc_sample *smp, const std::string &path, const CountOptions &opt, SampleStats *st) {
+    const double t_feed0 = now_s();
     TextFeeder feed(path, std::max<size_t>(opt.chunk_bytes, 1u << 16), 3, opt.io_threads, sgc_alloc_pinned, sgc_free_pinned,
                     opt.inflate_threads);
     if (feed.first_byte != '@') return false;
+    const double t_feed1 = now_s();
+    double t_first_push = -1;
     uint64_t first_line = 0;
     size_t carry = 0;                                  // bytes of an unfinished line, already sitting in front of the slice
     double t_push = 0, t_upwait = 0;
@@ -679,6 +685,7 @@ static bool count_fastq_text(sgc_sample *smp, const std::string &path, const Cou
             sgc_check(sgc_sample_push_fastq_part(smp, part, part_len, SGC_MEM_HOST, first_line, newlines, nullptr),
                       "sgc_sample_push_fastq_part");
             t_push += now_s() - t0;
+            if (t_first_push < 0) t_first_push = now_s() - t0;
             first_line += newlines + (part[part_len - 1] != '\n' ? 1 : 0);
             // the buffer of slice k - 1 may be refilled once its upload is through (this part's may still be in flight)
             t0 = now_s();
@@ -698,19 +705,78 @@ static bool count_fastq_text(sgc_sample *smp, const std::string &path, const Cou
         st->reader_threads = feed.n_threads;
         st->read_busy_s = feed.busy_s; st->read_wait_s = feed.wait_s; st->push_s = t_push; st->upload_wait_s = t_upwait;
         st->gz = feed.is_gz; st->bgzf = feed.is_bgzf;
+        st->feeder_setup_s = t_feed1 - t_feed0; st->first_push_s = t_first_push < 0 ? 0 : t_first_push;
     }
     return true;
 }
 
+// The host-scan path: the scanner's records, block by block, through a small ring of pinned buffers into
+// sgc_sample_push_packed_async (which batches them on the device: one count pass per 2^24 records).
+static const size_t SCAN_BUF_RECORDS = 1u << 20;        // records per pinned buffer (8 MB of one-word records)
+static const size_t SCAN_BUFS = 4;
+static void count_fastq_scan(sgc_sample *smp, FastqScanner &scan, SampleStats *st) {
+    const size_t words = scan.words, buf_bytes = SCAN_BUF_RECORDS * words * 8;
+    struct Ring {
+        uint8_t *b[SCAN_BUFS] = {};
+        ~Ring() { for (auto p : b) sgc_free_pinned(p); }
+    } ring;
+    const double t_a0 = now_s();
+    for (size_t i = 0; i < SCAN_BUFS; i++) {
+        ring.b[i] = (uint8_t *)sgc_alloc_pinned(buf_bytes);
+        if (!ring.b[i]) throw Error("cannot allocate pinned host buffers");
+    }
+    const double t_a1 = now_s();
+    double t_push = 0, t_upwait = 0, t_copy = 0;
+    size_t k = 0, fill = 0;                              // current buffer, records in it
+    auto push = [&]() {
+        if (!fill) return;
+        double t0 = now_s();
+        sgc_check(sgc_sample_push_packed_async(smp, ring.b[k % SCAN_BUFS], fill), "sgc_sample_push_packed_async");
+        t_push += now_s() - t0;
+        k++; fill = 0;
+        // the buffer about to be refilled was pushed SCAN_BUFS pushes ago (a push is one upload: a batch holds a whole number of buffers)
+        t0 = now_s();
+        sgc_check(sgc_sample_wait_uploads(smp, (uint32_t)(SCAN_BUFS - 1)), "sgc_sample_wait_uploads");
+        t_upwait += now_s() - t0;
+    };
+    const uint64_t *recs; size_t n;
+    while (scan.next(recs, n)) {
+        const double t0 = now_s();
+        size_t done = 0;
+        while (done < n) {
+            const size_t m = std::min(n - done, SCAN_BUF_RECORDS - fill);
+            memcpy(ring.b[k % SCAN_BUFS] + fill * words * 8, recs + done * words, m * words * 8);
+            fill += m; done += m;
+            if (fill == SCAN_BUF_RECORDS) { t_copy += now_s() - t0; push(); t_copy -= now_s() - t0; }
+        }
+        t_copy += now_s() - t0;
+        scan.release();
+    }
+    push();
+    sgc_check(sgc_sample_wait_uploads(smp, 0), "sgc_sample_wait_uploads");         // the ring is freed on return
+    if (st) {
+        st->text_bytes = scan.file_size; st->reader_threads = scan.n_threads;
+        st->read_busy_s = scan.busy_s; st->read_wait_s = scan.wait_s; st->push_s = t_push; st->upload_wait_s = t_upwait;
+        st->feeder_setup_s = t_a1 - t_a0; st->host_copy_s = t_copy; st->scan_path = true;
+    }
+}
+
 static SampleCounts count_sample(sgc_ctx *ctx, const std::string &path, const Offset &off, const Library &library,
-                                 const CountOptions &opt, SampleStats *st) {
+                                 const CountOptions &opt, SampleStats *st, std::unique_ptr<FastqScanner> scan) {
     const double t_begin = now_s();
     sgc_sample *smp = nullptr;
     sgc_check(sgc_sample_begin(ctx, &smp, off.reverse, (uint32_t)off.index, opt.position_recursion), "sgc_sample_begin");
     struct Guard { sgc_sample *s; ~Guard() { sgc_sample_free(s); } } guard{smp};
-    const bool parsed_on_device = opt.device_parse && opt.device_pack && count_fastq_text(smp, path, opt, st);
+    bool scanned = false;
+    if (scan && scan->usable) {
+        sgc_lib_info info;
+        sgc_check(sgc_library_info(ctx, &info), "sgc_library_info");
+        if (info.record_bytes == scan->words * 8) { count_fastq_scan(smp, *scan, st); scanned = true; }
+    }
+    scan.reset();
+    const bool parsed_on_device = !scanned && opt.device_parse && opt.device_pack && count_fastq_text(smp, path, opt, st);
     if (st) st->text_path = parsed_on_device;
-    if (!parsed_on_device) {
+    if (!parsed_on_device && !scanned) {
     FastxReader reader(path);                                                         // count.rs:24
     const uint32_t L = (uint32_t)library.size;
     sgc_lib_info info;
@@ -766,7 +832,7 @@ static SampleCounts count_sample(sgc_ctx *ctx, const std::string &path, const Of
 
 void count(const CountOptions &opt_in) {
     CountOptions opt = opt_in;
-    const double t_start = now_s();
+    const double t_start = now_s(), t_start_unix = unix_s();
     const Library library = Library::from_path(opt.library_path);                      // count.rs:87
     if (opt.genemap) {                                                                 // count.rs:90-95
         if (const std::string *missing = opt.genemap->missing_alias(library))
@@ -791,20 +857,42 @@ void count(const CountOptions &opt_in) {
     if (opt.max_devices > 0) n_dev = std::min(n_dev, (int)opt.max_devices);
     const size_t n_workers = std::max<size_t>(1, std::min(opt.threads, opt.input_paths.size()));
     const size_t n_ctx = std::min(opt.input_paths.size(), std::max<size_t>((size_t)n_dev, n_workers));
+    const size_t hw = usable_cpus();
     if (opt.io_threads == 0) {
-        const size_t hw = std::max(1u, std::thread::hardware_concurrency());
         opt.io_threads = std::max<size_t>(1, std::min<size_t>(8, hw / n_workers));
         opt.inflate_threads = std::max<size_t>(1, std::min<size_t>(16, hw / n_workers));      // BGZF members, inflated in parallel
     }
+    if (opt.scan_threads == 0) opt.scan_threads = std::max<size_t>(1, std::min<size_t>(16, (hw > 1 ? hw - 1 : 1) / n_workers));
+    // Host scan (default for plain FASTQ text when the library has a packed record format: ACGT guides, L <= 30): the
+    // scanners of the first samples start NOW, so that reading and packing the text overlap device start-up and the table
+    // build below — neither needs the other (count.rs:103-136 builds the Permuter, then fans the samples out; the order of
+    // the observable effects stays: a library or gene-map error was raised above, a malformed sample is reported when its
+    // turn comes).
+    bool packable = opt.host_scan && opt.device_pack && library.size >= 1 && library.size <= SGC_MAX_GUIDE_LEN;
+    for (size_t i = 0; packable && i < library.seqs.size(); i++)
+        for (char ch : library.seqs[i]) if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') { packable = false; break; }
+    std::vector<std::unique_ptr<FastqScanner>> scanners(opt.input_paths.size());
+    auto make_scanner = [&](size_t i) {
+        ScanParams sp;
+        sp.L = (uint32_t)library.size; sp.reverse = opt.offsets[i].reverse; sp.offset = (uint32_t)opt.offsets[i].index;
+        sp.recursion = opt.position_recursion;
+        return std::unique_ptr<FastqScanner>(new FastqScanner(opt.input_paths[i], sp, opt.scan_threads, opt.scan_block_bytes));
+    };
+    if (packable)
+        for (size_t i = 0; i < std::min(n_workers, opt.input_paths.size()); i++)
+            if (opt.offsets[i].index <= 0xFFFFFFFFull) scanners[i] = make_scanner(i);
     std::string flat;
     flat.reserve(library.seqs.size() * library.size);
     for (const auto &s : library.seqs) flat += s;
     std::vector<sgc_ctx *> ctxs;
     struct CtxGuard { std::vector<sgc_ctx *> &v; ~CtxGuard() { for (auto c : v) sgc_free(c); } } cg{ctxs};
     std::vector<int> ctx_dev;
+    double init_s = 0;
     for (size_t k = 0; k < n_ctx; k++) {
         sgc_ctx *c = nullptr;
+        const double t_i0 = now_s();
         sgc_check(sgc_init((int)(k % (size_t)n_dev), &c), "sgc_init");
+        init_s += now_s() - t_i0;
         ctxs.push_back(c);
         ctx_dev.push_back((int)(k % (size_t)n_dev));
         if (!opt.quiet && !opt.exact && k == 0) fprintf(stderr, "Generating Mismatch Library\n");
@@ -812,6 +900,7 @@ void count(const CountOptions &opt_in) {
                                   !opt.exact), "sgc_set_library");
         if (!opt.quiet && !opt.exact && k == 0) fprintf(stderr, "Finished Mismatch Library\n");
         if (!opt.stats_path.empty()) sgc_check(sgc_timing_enable(c, 1), "sgc_timing_enable");
+        sgc_check(sgc_set_option(c, "batch_records", (int64_t)(16 * SCAN_BUF_RECORDS)), "sgc_set_option");     // a whole number of pinned buffers
     }
     const double t_tables = now_s();
     // samples in parallel (count.rs:117-136: rayon over samples, pool size -t), results in input order
@@ -833,8 +922,10 @@ void count(const CountOptions &opt_in) {
                 if (!opt.quiet) fprintf(stderr, "Processing: %s\n", opt.sample_names[i].c_str());
                 std::lock_guard<std::mutex> lk(dev_mu[d]);      // one sample at a time per context
                 sample_dev[i] = ctx_dev[d];
+                std::unique_ptr<FastqScanner> sc = std::move(scanners[i]);
+                if (!sc && packable && opt.offsets[i].index <= 0xFFFFFFFFull) sc = make_scanner(i);
                 results[i] = count_sample(ctxs[d], opt.input_paths[i], opt.offsets[i], library, opt,
-                                          opt.stats_path.empty() ? nullptr : &stats[i]);
+                                          opt.stats_path.empty() ? nullptr : &stats[i], std::move(sc));
                 if (!opt.quiet)                                                           // count.rs:34-43
                     fprintf(stderr, "Finished: %s; Fraction mapped: %.3f [%llu / %llu]\n", opt.sample_names[i].c_str(),
                             (double)results[i].matched_reads / (double)results[i].total_reads,
@@ -855,20 +946,26 @@ void count(const CountOptions &opt_in) {
     const double t_counted = now_s();
     write_results(opt.output_path, results, library, opt.sample_names, opt.genemap, opt.include_zero);
     const double t_end = now_s();
+    scanners.clear();
+    for (auto c : ctxs) sgc_free(c);            // (the guard above covers the error paths)
+    ctxs.clear();
+    const double t_freed = now_s();
     if (!opt.stats_path.empty()) {
         FILE *f = fopen(opt.stats_path.c_str(), "wb");
         if (!f) throw Error("cannot create the stats file: " + opt.stats_path);
         fprintf(f, "{\"library_load_s\": %.6f, \"table_build_s\": %.6f, \"samples_s\": %.6f, \"table_write_s\": %.6f, \"total_s\": %.6f, "
+                   "\"device_init_s\": %.6f, \"context_free_s\": %.6f, \"count_entered_unix_s\": %.6f, \"stats_written_unix_s\": %.6f, "
                    "\"devices\": %d, \"contexts\": %zu, \"worker_threads\": %zu, \"samples\": [",
-                t_lib - t_start, t_tables - t_lib, t_counted - t_tables, t_end - t_counted, t_end - t_start, n_dev, ctxs.size(), n_threads);
+                t_lib - t_start, t_tables - t_lib, t_counted - t_tables, t_end - t_counted, t_end - t_start, init_s, t_freed - t_end, t_start_unix, unix_s(),
+                n_dev, n_ctx, n_threads);
         for (size_t i = 0; i < n; i++) {
             const SampleStats &x = stats[i];
-            fprintf(f, "%s{\"device\": %d, \"reads\": %llu, \"text_bytes\": %llu, \"gz\": %s, \"bgzf\": %s, \"text_path\": %s, \"reader_threads\": %zu, "
+            fprintf(f, "%s{\"device\": %d, \"reads\": %llu, \"text_bytes\": %llu, \"gz\": %s, \"bgzf\": %s, \"text_path\": %s, \"scan_path\": %s, \"host_copy_s\": %.6f, \"reader_threads\": %zu, "
                        "\"wall_s\": %.6f, \"read_busy_s\": %.6f, \"wait_for_text_s\": %.6f, \"push_s\": %.6f, \"wait_for_upload_s\": %.6f, "
-                       "\"finish_s\": %.6f, \"h2d_ms\": %.3f, \"ingest_kernels_ms\": %.3f, \"count_kernels_ms\": %.3f}",
+                       "\"finish_s\": %.6f, \"feeder_setup_s\": %.6f, \"first_push_s\": %.6f, \"h2d_ms\": %.3f, \"ingest_kernels_ms\": %.3f, \"count_kernels_ms\": %.3f}",
                     i ? ", " : "", sample_dev[i], (unsigned long long)x.reads, (unsigned long long)x.text_bytes, x.gz ? "true" : "false", x.bgzf ? "true" : "false",
-                    x.text_path ? "true" : "false", x.reader_threads, x.wall_s, x.read_busy_s, x.read_wait_s, x.push_s,
-                    x.upload_wait_s, x.finish_s, x.h2d_ms, x.ingest_ms, x.count_ms);
+                    x.text_path ? "true" : "false", x.scan_path ? "true" : "false", x.host_copy_s, x.reader_threads, x.wall_s, x.read_busy_s, x.read_wait_s, x.push_s,
+                    x.upload_wait_s, x.finish_s, x.feeder_setup_s, x.first_push_s, x.h2d_ms, x.ingest_ms, x.count_ms);
         }
         fprintf(f, "]}\n");
         fclose(f);

@@ -94,6 +94,9 @@ struct CountOptions {
     size_t threads = 1;
     bool device_pack = true;             // raw bytes → records on the GPU (else sgc_pack_reads_host)
     bool device_parse = true;            // FASTQ inputs: ship text, find record boundaries on the GPU
+    bool host_scan = true;               // plain FASTQ text + packable library: the host scans and packs (FastqScanner), 8 B/read are shipped
+    size_t scan_threads = 0;             // scanner threads per sample (0 = min(16, usable CPUs - 1) / worker threads)
+    size_t scan_block_bytes = 4u << 20;  // text per unit of scanner work
     size_t chunk_bytes = 64u << 20;      // bytes of text per slice (one upload) for device_parse
     size_t io_threads = 0;               // reader threads per sample for plain FASTQ (0 = min(8, cores / worker threads))
     size_t inflate_threads = 0;          // inflating threads per BGZF sample (set with io_threads == 0: min(16, cores / worker threads))
@@ -109,6 +112,9 @@ size_t count_newlines(const uint8_t *p, size_t n);
 struct SampleStats {                    // where one sample's wall time went (host side; device side from sgc_timing)
     double wall_s = 0, read_busy_s = 0, read_wait_s = 0, push_s = 0, upload_wait_s = 0, finish_s = 0;
     double h2d_ms = 0, ingest_ms = 0, count_ms = 0;
+    double host_copy_s = 0;             // scan path: block records -> pinned buffers (consumer thread)
+    bool scan_path = false;             // the host scanned and packed the text (FastqScanner); text_path: the GPU parsed it
+    double feeder_setup_s = 0, first_push_s = 0;   // pinned ring allocation + reader start; the first push (device scratch allocation)
     uint64_t text_bytes = 0, reads = 0;
     size_t reader_threads = 0;
     bool gz = false, bgzf = false, text_path = false;
@@ -161,6 +167,43 @@ class TextFeeder {
     bool stop = false, failed = false;
     std::string error;
 };
+// Plain FASTQ text -> packed records on the host (sgh_scan.cpp): the file is memory-mapped, `threads` workers take 4 MiB
+// blocks in file order (list the line starts, learn the block's first line number from the blocks before it, verify the
+// marker bytes, pack every sequence line's window into a record of sgc_format.h), the consumer takes the blocks' records
+// in order (the workers run at most max_ahead_blocks ahead of it: ~110 KB of records per 4 MiB block of 150-base reads).  usable == false: not a regular, non-empty file that starts with '@' (gzip, FASTA, a pipe): use the other readers.
+struct ScanParams { uint32_t L = 0; bool reverse = false; uint32_t offset = 0; bool recursion = true; };
+class FastqScanner {
+  public:
+    FastqScanner(const std::string &path, const ScanParams &prm, size_t threads, size_t block_bytes = 4u << 20, size_t max_ahead_blocks = 16384);
+    ~FastqScanner();
+    // the records of the next block (n_records records of `words` u64 each), in file order; false = end of file.  Throws
+    // Panic on a malformed record (wrong marker byte; a line count that is no multiple of 4 at the end).
+    bool next(const uint64_t *&recs, size_t &n_records);
+    void release();                     // the block returned by the last next() may be dropped
+    bool usable = true;
+    size_t file_size = 0, n_threads = 0, words = 1;
+    uint64_t total_lines = 0;           // after next() returned false
+    double busy_s = 0, wait_s = 0;      // Σ worker busy time; time the consumer waited for a block
+  private:
+    struct Block;
+    void run();
+    void extract(size_t b);
+    std::string path;
+    ScanParams prm;
+    int fd = -1;
+    const uint8_t *map = nullptr;
+    size_t end = 0, block = 0, n_blocks = 0, ahead = 0;
+    std::unique_ptr<Block[]> blocks;
+    size_t next_block = 0, chain = 0, consumed = 0;
+    uint64_t lines_so_far = 0;
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv;
+    bool stop = false, failed = false, checked_end = false;
+    std::string error;
+};
+size_t usable_cpus();                                    // affinity mask capped by the cgroup CPU quota
+
 int cli_main(int argc, char **argv);                     // main.rs:142-203; returns the process exit code
 
 }  // namespace sgh

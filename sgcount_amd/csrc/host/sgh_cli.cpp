@@ -26,12 +26,17 @@ static const char *USAGE =
     "  -t, --threads <THREADS>               Number of Threads to Use for Parallel Jobs [default: 1]\n"
     "  -q, --quiet                           Does not show progress\n"
     "  -z, --include-zero                    Include zero count sgRNAs in output table\n"
-    "      --pack <host|device|fastq>        Where reads are parsed/packed: host packer, GPU packer on host-parsed reads,\n"
-    "                                        or FASTQ text parsed on the GPU [default: fastq]\n"
-    "      --io-threads <N>                  Reader threads per sample for plain FASTQ text [default: min(8, cores/threads)]\n"
+    "      --pack <scan|fastq|device|host>   Where reads are parsed/packed: scan = the host scans the memory-mapped text with\n"
+    "                                        several threads and ships packed records (plain FASTQ; anything else falls\n"
+    "                                        through to fastq); fastq = the text is shipped and parsed on the GPU; device =\n"
+    "                                        record reader + GPU packer; host = record reader + host packer [default: scan]\n"
+    "      --scan-threads <N>                Scanner threads per sample for --pack scan [default: min(16, cpus - 1)/threads]\n"
+    "      --io-threads <N>                  Reader threads per sample for --pack fastq [default: min(8, cores/threads)]\n"
     "      --chunk-mb <MB>                   Text per upload [default: 64]\n"
     "      --devices <N>                     Use at most N of the visible GPUs [default: all]\n"
     "      --stats-json <PATH>               Write per-stage timings of the run as JSON\n"
+    "      --exit <fast|clean>               fast: _exit() once everything is written (skips the HIP runtime's teardown);\n"
+    "                                        clean: return through exit() [default: fast]\n"
     "  -h, --help                            Print help\n"
     "  -V, --version                         Print version\n";
 
@@ -75,14 +80,18 @@ int cli_main(int argc, char **argv) {
             else if (a == "--include-permutations") { /* BASELINE.json's name for the reference default; no-op */ }
             else if (a == "--pack") {
                 const std::string v = need(i, "--pack");
-                if (v != "host" && v != "device" && v != "fastq") throw Error("invalid value '" + v + "' for '--pack'");
+                if (v != "host" && v != "device" && v != "fastq" && v != "scan") throw Error("invalid value '" + v + "' for '--pack'");
                 opt.device_pack = v != "host";
-                opt.device_parse = v == "fastq";
+                opt.device_parse = v == "fastq" || v == "scan";
+                opt.host_scan = v == "scan";
             }
+            else if (a == "--scan-threads") opt.scan_threads = to_num(need(i, "--scan-threads"), "--scan-threads");
+            else if (a == "--scan-block-kb") opt.scan_block_bytes = to_num(need(i, "--scan-block-kb"), "--scan-block-kb") << 10;
             else if (a == "--io-threads") opt.io_threads = to_num(need(i, "--io-threads"), "--io-threads");
             else if (a == "--chunk-mb") opt.chunk_bytes = to_num(need(i, "--chunk-mb"), "--chunk-mb") << 20;
             else if (a == "--devices") opt.max_devices = to_num(need(i, "--devices"), "--devices");
             else if (a == "--stats-json") opt.stats_path = need(i, "--stats-json");
+            else if (a == "--exit") { const std::string v = need(i, "--exit"); if (v != "fast" && v != "clean") throw Error("invalid value '" + v + "' for '--exit'"); }
             else if (a == "-h" || a == "--help") { fputs(USAGE, stdout); return 0; }
             else if (a == "-V" || a == "--version") { puts("sgcount-hip 0.1.0 (count path of sgcount 0.1.35)"); return 0; }
             else { fprintf(stderr, "error: unexpected argument '%s' found\n\n%s", a.c_str(), USAGE); return 2; }
@@ -130,5 +139,15 @@ int cli_main(int argc, char **argv) {
 }  // namespace sgh
 
 #ifndef SGH_NO_MAIN
-int main(int argc, char **argv) { return sgh::cli_main(argc, argv); }
+#include <unistd.h>
+int main(int argc, char **argv) {
+    const int rc = sgh::cli_main(argc, argv);
+    // Everything observable is written and closed by now, the contexts are freed: end the process without the user-space
+    // teardown of the HIP runtime (static destructors, atexit handlers: 20-100 ms) — the kernel releases the device either
+    // way.  `--exit clean` returns through exit() instead (sanitizers, leak checkers).
+    for (int i = 1; i + 1 < argc; i++)
+        if (!strcmp(argv[i], "--exit") && !strcmp(argv[i + 1], "clean")) return rc;
+    fflush(stdout); fflush(stderr);
+    _exit(rc);
+}
 #endif

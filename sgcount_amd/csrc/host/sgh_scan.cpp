@@ -1,0 +1,320 @@
+// sgh_scan.cpp — FastqScanner: plain FASTQ text -> packed records, on the host, at memory speed.
+//
+// This is the host half of the count path as the north star draws it ("a host that streams FASTQ, 2-bit-packs reads into
+// u64 k-mers and ships pinned batches through a thin C-ABI HIP layer"): it replaces the fxread iterator and
+// Counter::apply_trim (reference src/counter.rs:144-204, 211-236) for plain-text samples.  Per read only the L + 2 oriented
+// bases [o - 1, o + L + 1) matter (sgc_format.h), so instead of shipping 316 bytes of text per read over PCIe and finding
+// the records on the GPU (the `--pack fastq` path, kept as the validated fallback), the reader threads find the lines in
+// the page cache and emit ONE 8-byte record per read: 40x fewer bytes on the link.
+//
+// The file is memory-mapped and never copied.  Why not pread(): the first read() of page-cache pages that were just written
+// (a tmpfs file above all: shmem_file_read_iter marks every page accessed) moves each of them to the active LRU list under
+// ONE lock — 16 GB/s in all however many threads read (profiles/r03/first_read_probe.txt: that was the 2 s the first run of
+// round 2's e2e leg lost).  A mapping does the same when its pages are unmapped with their accessed bits set — unless the
+// mapping is marked MADV_SEQUENTIAL (vma_has_recency(): the kernel then ignores those bits) — and MADV_POPULATE_READ /
+// MAP_POPULATE touch the pages the same way (FOLL_TOUCH), so the pages are simply faulted in by the scan (64 KiB per
+// fault) and dropped block by block with MADV_DONTNEED, in parallel rather than at exit.  Threads take 4 MiB blocks in
+// file order:
+//   phase 1   list the line starts of the block (AVX2 compare + movemask; SWAR fallback)
+//   chain     line number of the block's first line = sum of the line counts of all earlier blocks (published in order)
+//   phase 2   walk the lines: marker bytes of header ('@') and separator ('+') lines are verified, every sequence line
+//             becomes a record (fast path: all L + 2 window bytes present and ACGT -> pshufb + pext; anything else goes
+//             through sgc_pack_one, the same function the device packers restate)
+// and the consumer takes the blocks' records in order.  A '\r' before the '\n' belongs to the terminator, trailing blank
+// lines at the end of the file are not records, a line count that is no multiple of 4 is a truncated record — the rules
+// of the other readers.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+#include "../sgc_format.h"
+#include "sgh.hpp"
+
+namespace sgh {
+
+static double scan_now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// CPUs this process may actually use: the affinity mask, capped by the cgroup's CPU quota (a container sees all the
+// host's CPUs in hardware_concurrency() but is throttled to its quota)
+size_t usable_cpus() {
+    size_t n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min<size_t>(n, (size_t)std::max(1, CPU_COUNT(&set)));
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0};
+        unsigned long long period = 0;
+        if (fscanf(f, "%63s %llu", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            const unsigned long long quota = strtoull(q, nullptr, 10);
+            if (quota > 0) n = std::min<size_t>(n, (size_t)std::max<unsigned long long>(1, (quota + period / 2) / period));
+        }
+        fclose(f);
+    }
+    return n;
+}
+
+// ---- line starts of a byte range ------------------------------------------------------------------------
+// appends p + 1 - base for every '\n' at p in [lo, hi)
+static void list_newlines_generic(const uint8_t *t, size_t lo, size_t hi, size_t base, std::vector<uint32_t> &out) {
+    for (size_t p = lo; p < hi;) {
+        const void *q = memchr(t + p, '\n', hi - p);
+        if (!q) break;
+        p = (size_t)((const uint8_t *)q - t);
+        out.push_back((uint32_t)(p + 1 - base));
+        p++;
+    }
+}
+
+#if defined(__x86_64__)
+__attribute__((target("avx2,bmi"))) static void list_newlines_avx2(const uint8_t *t, size_t lo, size_t hi, size_t base,
+                                                                    std::vector<uint32_t> &out) {
+    const __m256i nl = _mm256_set1_epi8('\n');
+    size_t n = out.size();
+    out.resize(n + 1024);
+    uint32_t *w = out.data();
+    size_t p = lo;
+    for (; p + 64 <= hi; p += 64) {
+        const __m256i a = _mm256_loadu_si256((const __m256i *)(t + p)), b = _mm256_loadu_si256((const __m256i *)(t + p + 32));
+        uint64_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(a, nl)) |
+                     ((uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(b, nl)) << 32);
+        if (!m) continue;
+        if (n + 64 > out.size()) { out.resize(out.size() * 2 + 64); w = out.data(); }
+        const uint32_t rel = (uint32_t)(p + 1 - base);
+        while (m) { w[n++] = rel + (uint32_t)__builtin_ctzll(m); m &= m - 1; }
+    }
+    out.resize(n);
+    list_newlines_generic(t, p, hi, base, out);
+}
+#endif
+
+static bool have_avx2() {
+#if defined(__x86_64__)
+    static const bool v = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("bmi");
+    return v;
+#else
+    return false;
+#endif
+}
+
+// ---- one read -> one record --------------------------------------------------------------------------------
+// Fast path: the K = L + 2 window bytes all exist and are ACGT.  Returns false when the general packer must decide.
+#if defined(__x86_64__)
+__attribute__((target("avx2,bmi2"))) static bool pack_fast_avx2(const uint8_t *win /* K bytes in FILE order, 32 readable */, uint32_t K,
+                                                                bool reverse, uint64_t &span) {
+    const __m256i v = _mm256_loadu_si256((const __m256i *)win);
+    // by low nibble: 'A' 0x41 -> 1, 'C' 0x43 -> 3, 'T' 0x54 -> 4, 'G' 0x47 -> 7; the other entries hold a byte whose own low
+    // nibble differs from their index, so no input byte can equal them
+    const __m256i want = _mm256_setr_epi8(1, 'A', 0, 'C', 'T', 0, 0, 'G', 0, 0, 0, 0, 0, 0, 0, 0, 1, 'A', 0, 'C', 'T', 0, 0, 'G', 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i code = _mm256_setr_epi8(0, 0, 0, 1, 3, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 3, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0);
+    const __m256i nib = _mm256_and_si256(v, _mm256_set1_epi8(0x0F));
+    const uint32_t ok = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_shuffle_epi8(want, nib), v));
+    const uint32_t need = K >= 32 ? 0xFFFFFFFFu : ((1u << K) - 1u);
+    if ((ok & need) != need) return false;
+    const __m256i c = _mm256_shuffle_epi8(code, nib);
+    alignas(32) uint64_t q[4];
+    _mm256_store_si256((__m256i *)q, c);
+    const uint64_t M = 0x0303030303030303ull;
+    uint64_t x = _pext_u64(q[0], M) | (_pext_u64(q[1], M) << 16) | (_pext_u64(q[2], M) << 32) | (_pext_u64(q[3], M) << 48);
+    const uint64_t kmask = K >= 32 ? ~0ull : ((1ull << (2 * K)) - 1ull);
+    if (reverse) {
+        // oriented base w = complement of file base K - 1 - w: reverse the 2-bit groups of the 64-bit word, drop the
+        // 32 - K groups that end up below, complement (3 - code)
+        x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+        x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+        x = __builtin_bswap64(x);
+        x = (x >> (64 - 2 * K)) ^ kmask;
+    }
+    span = x & kmask;
+    return true;
+}
+#endif
+
+struct FastqScanner::Block {
+    std::vector<uint32_t> starts;      // line starts relative to the block's first byte (phase 1; dropped after phase 2)
+    std::vector<uint64_t> recs;        // phase 2: the records of the sequence lines that START in this block
+    uint64_t first_line = 0;           // global number of the block's first line
+    uint64_t bad_line = 0;             // 1-based number of the first line whose marker byte is wrong (0 = none)
+    bool scanned = false, done = false;
+};
+
+FastqScanner::FastqScanner(const std::string &path_, const ScanParams &prm_, size_t threads, size_t block_bytes, size_t max_ahead)
+    : path(path_), prm(prm_) {
+    fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) throw Error("No such file or directory (os error 2): " + path);
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { close(fd); fd = -1; usable = false; return; }
+    file_size = (size_t)sb.st_size;
+    if (file_size == 0) { usable = false; return; }
+    void *m = mmap(nullptr, file_size, PROT_READ, MAP_SHARED, fd, 0);
+    if (m == MAP_FAILED) { usable = false; return; }
+    map = (const uint8_t *)m;
+    (void)madvise(m, file_size, MADV_SEQUENTIAL);            // see the head of this file: no LRU activation when the blocks are unmapped
+    (void)posix_fadvise(fd, 0, 0, POSIX_FADV_NOREUSE);
+    if (map[0] != '@') { usable = false; return; }          // gzip, FASTA, anything else: the other readers decide
+    // trailing blank lines at the very end are not records
+    end = file_size;
+    while (end >= 2 && map[end - 1] == '\n' && map[end - 2] == '\n') end--;
+    block = std::max<size_t>(block_bytes, 4096) & ~(size_t)4095;
+    n_blocks = (end + block - 1) / block;
+    blocks.reset(new Block[n_blocks]);
+    ahead = std::max<size_t>(max_ahead, 2);
+    words = prm.L > SGC_REC8_MAXL ? 2 : 1;
+    n_threads = std::max<size_t>(1, std::min(threads, n_blocks));
+    for (size_t t = 0; t < n_threads; t++) workers.emplace_back([this] { run(); });
+}
+
+FastqScanner::~FastqScanner() {
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        stop = true;
+    }
+    cv.notify_all();
+    for (auto &w : workers) if (w.joinable()) w.join();
+    blocks.reset();
+    if (map) munmap((void *)map, file_size);
+    if (fd >= 0) close(fd);
+}
+
+void FastqScanner::run() {
+    try {
+        for (;;) {
+            size_t b;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || failed || next_block >= n_blocks || next_block < consumed + ahead; });
+                if (stop || failed || next_block >= n_blocks) return;
+                b = next_block++;
+            }
+            const double t0 = scan_now_s();
+            Block &blk = blocks[b];
+            const size_t lo = b * block, hi = std::min(end, lo + block);
+            const size_t map_hi = std::min(file_size, (hi + 4095) & ~(size_t)4095);
+            // phase 1: the lines that start in [lo, hi): after every '\n' at [lo - 1, hi - 1), and at 0
+            blk.starts.reserve((hi - lo) / 64 + 16);
+            if (b == 0) blk.starts.push_back(0);
+            const size_t s_lo = lo ? lo - 1 : 0, s_hi = hi - 1;
+#if defined(__x86_64__)
+            if (have_avx2()) list_newlines_avx2(map, s_lo, s_hi, lo, blk.starts);
+            else
+#endif
+                list_newlines_generic(map, s_lo, s_hi, lo, blk.starts);
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                blk.scanned = true;
+                while (chain < n_blocks && blocks[chain].scanned) {
+                    blocks[chain].first_line = lines_so_far;
+                    lines_so_far += blocks[chain].starts.size();
+                    chain++;
+                }
+                cv.notify_all();
+                cv.wait(lk, [&] { return stop || failed || chain > b; });
+                if (stop || failed) return;
+            }
+            extract(b);
+            (void)madvise((void *)(map + lo), map_hi - lo, MADV_DONTNEED);      // drop the block's page-table entries here, in parallel, not at exit
+            const double dt = scan_now_s() - t0;
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                blk.done = true;
+                busy_s += dt;
+            }
+            cv.notify_all();
+        }
+    } catch (const std::exception &e) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!failed) { failed = true; error = e.what(); }
+        cv.notify_all();
+    }
+}
+
+// phase 2 of block b
+void FastqScanner::extract(size_t b) {
+    Block &blk = blocks[b];
+    const size_t lo = b * block;
+    const size_t ns = blk.starts.size();
+    const uint32_t L = prm.L, K = L + 2, o = prm.offset;
+    const bool rev = prm.reverse, rec = prm.recursion;
+    const uint32_t sh = 2 * K;
+    // status of a read whose K window bytes are all there and all ACGT: C clean; P and M clean with recursion (o >= 1 is a
+    // condition of the fast path), dead without
+    const uint64_t fast_status = rec ? 0ull : (uint64_t)K * (1ull + K) * SGC_STATE_DEAD;
+    const bool fast_ok = have_avx2() && o >= 1;
+    blk.recs.reserve((ns / 4 + 2) * words);
+    uint64_t g = blk.first_line;
+    for (size_t i = 0; i < ns; i++, g++) {
+        const size_t s = lo + blk.starts[i];
+        const uint32_t ph = (uint32_t)(g & 3u);
+        if (ph == 0 || ph == 2) {
+            if (map[s] != (ph == 0 ? '@' : '+') && !blk.bad_line) blk.bad_line = g + 1;
+            continue;
+        }
+        if (ph == 3) continue;
+        // sequence line [s, e)
+        size_t e;
+        if (i + 1 < ns) e = lo + blk.starts[i + 1] - 1;
+        else {
+            const void *q = memchr(map + s, '\n', end - s);
+            e = q ? (size_t)((const uint8_t *)q - map) : end;
+        }
+        size_t n = e - s;
+        if (n && map[s + n - 1] == '\r') n--;
+        uint64_t span = 0, status = 0;
+        bool done = false;
+#if defined(__x86_64__)
+        if (fast_ok && n >= (size_t)o + L + 1) {
+            const size_t w0 = rev ? s + n - o - L - 1 : s + o - 1;           // first window byte in file order
+            if (w0 + 32 <= file_size) {
+                done = pack_fast_avx2(map + w0, K, rev, span);
+                status = fast_status;
+            }
+        }
+#endif
+        if (!done) sgc_pack_one(map + s, n, L, rev ? 1 : 0, o, rec ? 1 : 0, span, status);
+        if (words == 2) { blk.recs.push_back(span); blk.recs.push_back(status); }
+        else blk.recs.push_back(span | (status << sh));
+    }
+    std::vector<uint32_t>().swap(blk.starts);
+}
+
+bool FastqScanner::next(const uint64_t *&recs, size_t &n_records) {
+    const double t0 = scan_now_s();
+    std::unique_lock<std::mutex> lk(mu);
+    if (consumed >= n_blocks) {
+        if (!checked_end) {
+            checked_end = true;
+            total_lines = lines_so_far;
+            if (lines_so_far % 4 != 0) throw Panic("truncated FASTQ record in " + path);
+        }
+        return false;
+    }
+    cv.wait(lk, [&] { return failed || blocks[consumed].done; });
+    wait_s += scan_now_s() - t0;
+    if (failed) throw Error(error);
+    Block &blk = blocks[consumed];
+    if (blk.bad_line)
+        throw Panic("malformed FASTQ record: line " + std::to_string(blk.bad_line) +
+                    " does not start with its marker byte ('@' header / '+' separator) in " + path);
+    recs = blk.recs.data();
+    n_records = blk.recs.size() / words;
+    return true;
+}
+
+void FastqScanner::release() {
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (consumed < n_blocks) { std::vector<uint64_t>().swap(blocks[consumed].recs); consumed++; }
+    }
+    cv.notify_all();
+}
+
+}  // namespace sgh

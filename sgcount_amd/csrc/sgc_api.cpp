@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <new>
 #include <string>
 #include <utility>
@@ -99,6 +100,7 @@ struct sgc_ctx {
     uint32_t dbg = 0;           // timing-only ablation flags (results are wrong when non-zero)
     uint32_t k1_wgs = 512;      // workgroups of the partition kernel: two per CU (more leave more half-empty blocks open, fewer expose its phases)
     uint64_t max_chunk = 1ull << 27;   // records per internal pass (bounds the scratch buffers)
+    uint64_t batch_records = 1ull << 24;   // sgc_sample_push_packed_async: records per device-side batch (one count pass each)
     bool rest_filter = true;           // core pass A settles "no parent inside the core" with the rest filter (sgc_format.h)
     bool align_slices = true;          // build the library table with slices that follow the core hash (next sgc_set_library)
     bool host_build = false;           // build the single-mismatch table on the host (sgc_tables.cpp) instead of the GPU
@@ -122,6 +124,13 @@ struct sgc_sample {
     uint64_t total = 0;
     uint64_t since_fold = 0;     // reads counted into d_c32 since the last fold (u32 overflow guard)
     size_t state_bytes = 0;
+    // sgc_sample_push_packed_async: two device batch buffers, filled by the upload stream, counted when full
+    void *d_acc[2] = {nullptr, nullptr};
+    hipEvent_t ev_acc_use[2] = {nullptr, nullptr};   // the count pass that read d_acc[i] is done
+    bool acc_used[2] = {false, false};
+    uint64_t acc_cap = 0, acc_fill = 0;              // records
+    int acc_cur = 0;
+    hipEvent_t acc_last_up = nullptr;                // the most recent upload into the current batch
 };
 
 // ---- helpers -------------------------------------------------------------------------------------
@@ -490,6 +499,10 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
         if (value < 1 || value > (int64_t)(1ll << 28)) return fail(SGC_E_ARG, "max_chunk out of range (1 .. 2^28: the partition kernel addresses its pool with 32-bit byte offsets)");
         c->max_chunk = (uint64_t)value; return SGC_OK;
     }
+    if (!strcmp(key, "batch_records")) {
+        if (value < 1 || value > (int64_t)(1ll << 28)) return fail(SGC_E_ARG, "batch_records out of range (1 .. 2^28)");
+        c->batch_records = (uint64_t)value; return SGC_OK;          // takes effect for samples that have not pushed asynchronously yet
+    }
     if (!strcmp(key, "align_slices")) { c->align_slices = value != 0; return SGC_OK; }       // takes effect at the next sgc_set_library
     if (!strcmp(key, "force_bytes")) { c->force_bytes = value != 0; return SGC_OK; }         // takes effect at the next sgc_set_library
     if (!strcmp(key, "dense")) { c->dense = value != 0; return SGC_OK; }
@@ -588,15 +601,25 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
     std::vector<uint64_t> keys;
     sgc_host_table h_lib, h_perm;
     std::string err;
+    // option "verbose": where the time of this call goes, phase by phase (stderr)
+    auto lap_t = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!c->verbose) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "sgc_set_library: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - lap_t).count());
+        lap_t = now;
+    };
     if (c->force_bytes && L >= 1 && n >= 1) return set_library_bytes(c, seqs, n, L, enable_1mm != 0);
     const uint32_t want_cl = (c->align_slices && L >= 4 && L <= SGC_REC8_MAXL) ? (L - 2) / 2 : 0;
     int rc = sgc_build_library_table(seqs, n, L, SGC_LDS_LOG2_SLICE, want_cl, keys, h_lib, err);
     if (rc == SGC_E_UNSUPPORTED && L >= 1 && n >= 1) return set_library_bytes(c, seqs, n, L, enable_1mm != 0);
     if (rc != SGC_OK) return fail(rc, "sgc_set_library: " + err);
+    lap("library table (host)");
     rc = upload_table(h_lib, &c->d_lib_slots, &c->d_lib_vals, &c->v_lib, c->stream);
     if (rc != SGC_OK) { free_tables(c); return rc; }
     rc = upload_bloom(keys, SGC_LIB_BLOOM_LOG2_WORDS, &c->d_bloom_lib, &c->b_lib, c->stream);
     if (rc != SGC_OK) { free_tables(c); return rc; }
+    lap("upload + library filter");
     if (sgc_part_supported(c->v_lib, L > SGC_REC8_MAXL)) {
         // the partitioned path probes a two-choice image of every slice (k_count_slices<CUCKOO>)
         std::vector<uint64_t> ck;
@@ -608,6 +631,7 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
             if (e != hipSuccess) { free_tables(c); return fail(e == hipErrorOutOfMemory ? SGC_E_OOM : SGC_E_HIP, std::string("sgc_set_library: ") + hipGetErrorString(e)); }
         }
     }
+    lap("two-choice slice image");
     c->v_perm = sgc_table_view{nullptr, nullptr, 0, h_lib.gid_bits, 0, 0};
     c->perm_entries = 0;
     std::vector<uint64_t> amb;
@@ -657,6 +681,7 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
             if (rc != SGC_OK) { free_tables(c); return rc; }
         }
     }
+    lap("single-mismatch table");
     {
         // core indexes (variant 4): span bases [2, L) cut in two; absent => the probing resolver stays in charge.  Built for -x
         // too: there one exact-only pass over core A takes the place of the probing resolver (k_core<EXACT>)
@@ -666,8 +691,10 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
             if (sgc_build_core_index(keys, L, 2, ca, hc[0]) && sgc_build_core_index(keys, L, 2 + ca, L - 2 - ca, hc[1])) {
                 hipError_t e = hipSuccess;
                 std::vector<uint32_t> filt;
+                lap("core indexes (host)");
                 const uint32_t fl2 = sgc_rest_filter_log2(n);
                 if (c->rest_filter && enable_1mm) sgc_build_rest_filter(keys, hc[0].cs, hc[0].cl, fl2, filt);
+                lap("rest filter (host)");
                 for (int k = 0; k < 2 && e == hipSuccess; k++) {
                     e = hipMalloc((void **)&c->d_core_ents[k], hc[k].ents.size() * 8);
                     if (e == hipSuccess) e = hipMalloc((void **)&c->d_core_gids[k], hc[k].gids.size() * 4);
@@ -694,6 +721,7 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
                     return fail(e == hipErrorOutOfMemory ? SGC_E_OOM : SGC_E_HIP, std::string("sgc_set_library: core index upload: ") + hipGetErrorString(e));
                 }
                 c->has_core = true;
+                lap("core index upload");
             }
         }
     }
@@ -823,6 +851,7 @@ int sgc_sample_reset(sgc_sample *s) {
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(s->d_c64, 0, s->state_bytes, c->stream));
     s->total = 0; s->since_fold = 0; s->fastq_pushed = false;
+    s->acc_fill = 0; s->acc_last_up = nullptr;        // records uploaded but not yet counted are dropped with the counts
     return SGC_OK;
 }
 
@@ -830,6 +859,8 @@ void sgc_sample_free(sgc_sample *s) {
     if (!s) return;
     hipSetDevice(s->ctx->device);
     hipStreamSynchronize(s->ctx->stream);
+    if (s->d_acc[0] || s->d_acc[1]) hipStreamSynchronize(s->ctx->copy_stream);
+    for (int i = 0; i < 2; i++) { if (s->d_acc[i]) hipFree(s->d_acc[i]); if (s->ev_acc_use[i]) hipEventDestroy(s->ev_acc_use[i]); }
     if (s->d_c64) hipFree(s->d_c64);
     delete s;
 }
@@ -853,6 +884,59 @@ int sgc_sample_push_packed(sgc_sample *s, const void *records, uint64_t n, int w
         return fail(SGC_E_ARG, "sgc_sample_push_packed: where must be SGC_MEM_HOST or SGC_MEM_DEVICE");
     }
     return count_records(s, d, n);
+}
+
+// the records uploaded into the current batch buffer so far -> one count pass (after their uploads, on the ctx stream)
+static int flush_batch(sgc_sample *s) {
+    if (s->acc_fill == 0) return SGC_OK;
+    sgc_ctx *c = s->ctx;
+    const int cur = s->acc_cur;
+    if (s->acc_last_up) HIP_TRY(hipStreamWaitEvent(c->stream, s->acc_last_up, 0));
+    const uint64_t n = s->acc_fill;
+    s->acc_fill = 0; s->acc_cur = cur ^ 1; s->acc_last_up = nullptr;
+    const int rc = count_records(s, (const uint64_t *)s->d_acc[cur], n);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(s->ev_acc_use[cur], c->stream));
+    s->acc_used[cur] = true;
+    return SGC_OK;
+}
+
+int sgc_sample_push_packed_async(sgc_sample *s, const void *records, uint64_t n) {
+    if (!s || (!records && n)) return fail(SGC_E_ARG, "sgc_sample_push_packed_async: NULL argument");
+    if (n == 0) return SGC_OK;
+    sgc_ctx *c = s->ctx;
+    if (c->bytes_mode)
+        return fail(SGC_E_STATE, "sgc_sample_push_packed_async: this library has no packed record format (sgc_library_info: record_bytes == 0)");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t rb = c->rec16 ? 16 : 8;
+    if (!s->d_acc[0]) {
+        s->acc_cap = c->batch_records;
+        for (int i = 0; i < 2; i++) {
+            hipError_t e = hipMalloc(&s->d_acc[i], (size_t)s->acc_cap * rb);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_acc_use[i], hipEventDisableTiming);
+            if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? SGC_E_OOM : SGC_E_HIP, std::string("sgc_sample_push_packed_async: ") + hipGetErrorString(e));
+        }
+    }
+    const uint8_t *src = (const uint8_t *)records;
+    while (n) {
+        const int cur = s->acc_cur;
+        const uint64_t m = std::min<uint64_t>(n, s->acc_cap - s->acc_fill);
+        // a batch buffer is overwritten only after the count pass that read it
+        if (s->acc_fill == 0 && s->acc_used[cur]) HIP_TRY(hipStreamWaitEvent(c->copy_stream, s->ev_acc_use[cur], 0));
+        hipEvent_t up = c->ev_up[c->n_up % sgc_ctx::UP_RING];
+        if (c->n_up >= (uint64_t)sgc_ctx::UP_RING) HIP_TRY(hipEventSynchronize(up));      // at most UP_RING uploads in flight
+        {
+            timed t(c, T_H2D, false, c->copy_stream);
+            HIP_TRY(hipMemcpyAsync((char *)s->d_acc[cur] + (size_t)s->acc_fill * rb, src, (size_t)m * rb, hipMemcpyHostToDevice, c->copy_stream));
+        }
+        HIP_TRY(hipEventRecord(up, c->copy_stream));
+        c->n_up++;
+        s->acc_last_up = up;
+        s->acc_fill += m;
+        src += (size_t)m * rb; n -= m;
+        if (s->acc_fill == s->acc_cap) { const int rc = flush_batch(s); if (rc) return rc; }
+    }
+    return SGC_OK;
 }
 
 int sgc_sample_push_reads(sgc_sample *s, const uint8_t *seqs, const uint64_t *offsets, uint64_t n, int where) {
@@ -1014,6 +1098,7 @@ static int check_fastq_errors(sgc_sample *s) {
 int sgc_sample_sync(sgc_sample *s) {
     if (!s) return fail(SGC_E_ARG, "sgc_sample_sync: NULL");
     HIP_TRY(hipSetDevice(s->ctx->device));
+    { const int rc = flush_batch(s); if (rc) return rc; }
     HIP_TRY(hipStreamSynchronize(s->ctx->stream));
     return check_fastq_errors(s);
 }
@@ -1022,6 +1107,7 @@ int sgc_sample_flush(sgc_sample *s) {
     if (!s) return fail(SGC_E_ARG, "sgc_sample_flush: NULL");
     sgc_ctx *c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
+    { const int rc = flush_batch(s); if (rc) return rc; }
     sgc_launch_fold(c->stream, s->d_c32, s->d_c64, c->n);
     HIP_TRY(hipGetLastError());
     s->since_fold = 0;
@@ -1034,6 +1120,7 @@ int sgc_sample_export_device(sgc_sample *s, uint64_t *d_out) {
     if (!s || !d_out) return fail(SGC_E_ARG, "sgc_sample_export_device: NULL");
     sgc_ctx *c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
+    { const int rc = flush_batch(s); if (rc) return rc; }
     // fold + export in one launch: d_out = counts64 (+= counts32) | total | matched
     sgc_launch_export(c->stream, s->d_c32, s->d_c64, s->d_matched, s->total, c->n, (unsigned long long *)d_out);
     HIP_TRY(hipGetLastError());

@@ -27,7 +27,7 @@ def load():
         L.sgh_last_error.restype = C.c_char_p
         for name in ("sgh_cli", "sgh_entropy_offset_group", "sgh_positional_entropy", "sgh_minimize_mse",
                      "sgh_generate_sample_names", "sgh_genemap_get", "sgh_genemap_missing", "sgh_generate_columns",
-                     "sgh_format_results", "sgh_library_info", "sgh_fastx_stats", "sgh_text_feeder_walk"):
+                     "sgh_format_results", "sgh_library_info", "sgh_fastx_stats", "sgh_text_feeder_walk", "sgh_scan_records"):
             getattr(L, name).restype = C.c_int
         _lib = L
     return _lib
@@ -126,6 +126,23 @@ def text_feeder_walk(path, slice_bytes=1 << 16, threads=3):
     _chk(load().sgh_text_feeder_walk(path.encode(), C.c_uint64(slice_bytes), C.c_uint64(threads), C.byref(parts), C.byref(nbytes),
                                      C.byref(lines), C.byref(fnv), C.byref(fb), C.byref(gz)))
     return parts.value, nbytes.value, lines.value, fnv.value, fb.value, ("bgzf" if gz.value & 2 else bool(gz.value))
+
+
+def scan_records(path, L, reverse=False, offset=0, recursion=True, threads=3, block_bytes=1 << 16, cap=None):
+    """All packed records of a plain FASTQ file as the scan path produces them (FastqScanner: memory-mapped text, several
+    threads, blocks in order).  Returns (records as a uint64 array [n, words], total lines) or None if the scanner declines
+    the file (not plain FASTQ text).  Raises HostError 101 on a malformed / truncated record."""
+    words = 2 if L > 23 else 1
+    if cap is None:
+        cap = os.path.getsize(path) // 4 + 16          # a record takes at least 4 newlines... of text
+    out = np.zeros((cap, words), dtype=np.uint64)
+    n, lines, usable = C.c_uint64(), C.c_uint64(), C.c_int()
+    _chk(load().sgh_scan_records(path.encode(), C.c_uint32(L), int(bool(reverse)), C.c_uint32(offset), int(bool(recursion)),
+                                 C.c_uint64(threads), C.c_uint64(block_bytes), out.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                 C.c_uint64(cap), C.byref(n), C.byref(lines), C.byref(usable)))
+    if not usable.value:
+        return None
+    return out[: n.value], lines.value
 
 
 def cli(argv):

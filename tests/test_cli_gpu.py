@@ -53,7 +53,7 @@ def test_single_sample_fixed_offset_exact(cli, example_library_text, example_rea
     assert err == ""
 
 
-@pytest.mark.parametrize("pack", ["fastq", "device", "host"])
+@pytest.mark.parametrize("pack", ["scan", "fastq", "device", "host"])
 def test_all_samples_auto_offset_genemap_zero(cli, pack, tmp_path, example_library_text, example_reads):
     paths = [os.path.join(DATA, n + ".fastq.gz") for n in NAMES]
     g2s = os.path.join(DATA, "g2s.txt")
@@ -112,7 +112,7 @@ def test_error_paths(cli, tmp_path):
     assert code == 0 and "--library-path" in out and "--no-position-recursion" in out
 
 
-@pytest.mark.parametrize("pack", ["fastq", "device", "host"])
+@pytest.mark.parametrize("pack", ["scan", "fastq", "device", "host"])
 def test_library_with_n_and_long_guides(cli, pack, tmp_path):
     """Libraries the packed records cannot carry (an 'N' inside a guide; 34-base guides) go through the byte-string path
     (sgc_bytes.h) whatever --pack says: same table as the oracle, which compares bytes like the reference does."""
@@ -159,20 +159,39 @@ def test_python_count_wrapper(tmp_path, example_library_text, example_reads):
 
 
 def test_stats_json_and_plain_text_pipeline(cli, tmp_path, example_library_text, example_reads):
-    """The streaming text path on a plain (uncompressed) file with tiny slices and several reader threads: same table
-    as the oracle, and --stats-json reports the stages."""
+    """The two streaming paths on a plain (uncompressed) file, with tiny units of work and several threads: the default host
+    scan (FastqScanner -> packed records -> sgc_sample_push_packed_async) and the GPU-parsed text (--pack fastq: tiny slices,
+    several reader threads) give the oracle's table, and --stats-json reports the stages of each."""
     import json
     text = example_reads["diff.sequence"]
     fq = os.path.join(str(tmp_path), "diff.fastq")
     open(fq, "wb").write(text)
     stats = os.path.join(str(tmp_path), "stats.json")
-    rc, out, err = run(cli, "-l", LIB, "-i", fq, "-a", "5", "-q", "--io-threads", "3", "--chunk-mb", "0", "--stats-json", stats)
+    want = oracle_table(example_library_text, [text], ["diff"], [(False, 5)], False, True)
+    rc, out, err = run(cli, "-l", LIB, "-i", fq, "-a", "5", "-q", "--scan-threads", "3", "--scan-block-kb", "4", "--stats-json", stats)
     assert rc == 0, err
-    assert out == oracle_table(example_library_text, [text], ["diff"], [(False, 5)], False, True)
+    assert out == want
     st = json.load(open(stats))
     s0 = st["samples"][0]
-    assert s0["text_path"] and not s0["gz"] and s0["reads"] == 1101 and s0["reader_threads"] == 3
+    assert s0["scan_path"] and not s0["text_path"] and not s0["gz"] and s0["reads"] == 1101 and s0["reader_threads"] == 3
+    assert s0["text_bytes"] == len(text) and st["total_s"] > 0 and s0["count_kernels_ms"] > 0 and s0["h2d_ms"] > 0
+    rc, out, err = run(cli, "-l", LIB, "-i", fq, "-a", "5", "-q", "--pack", "fastq", "--io-threads", "3", "--chunk-mb", "0", "--stats-json", stats)
+    assert rc == 0, err
+    assert out == want
+    st = json.load(open(stats))
+    s0 = st["samples"][0]
+    assert s0["text_path"] and not s0["scan_path"] and not s0["gz"] and s0["reads"] == 1101 and s0["reader_threads"] == 3
     assert s0["text_bytes"] == len(text) and st["total_s"] > 0 and s0["ingest_kernels_ms"] > 0 and s0["count_kernels_ms"] > 0
+    # reverse strand, no recursion, several samples over two worker threads: scan path == GPU-parsed text == oracle
+    fq2 = os.path.join(str(tmp_path), "seq.fastq")
+    open(fq2, "wb").write(example_reads["sequence"])
+    outs = []
+    for pack in ("scan", "fastq"):
+        rc, out, err = run(cli, "-l", LIB, "-i", fq, fq2, "-a", "5", "-r", "-p", "-q", "-t", "2", "--pack", pack, "-z")
+        assert rc == 0, err
+        outs.append(out)
+    assert outs[0] == outs[1] == oracle_table(example_library_text, [text, example_reads["sequence"]], ["diff", "seq"],
+                                              [(True, 5), (True, 5)], False, False, include_zero=True)
 
 
 def test_bgzf_input_is_inflated_in_parallel(cli, tmp_path, example_library_text, example_reads):
@@ -207,7 +226,7 @@ def test_malformed_fastq_panics_like_the_reference(cli, tmp_path, example_reads)
     for name, body in (("bad_plus.fastq", b"\n".join(bad)), ("trunc.fastq", b"\n".join(lines[: 4 * 700 + 2]) + b"\n")):
         p = os.path.join(str(tmp_path), name)
         open(p, "wb").write(body)
-        for pack in ("fastq", "device"):
+        for pack in ("scan", "fastq", "device"):
             rc, out, err = run(cli, "-l", LIB, "-i", p, "-a", "5", "-q", "--pack", pack)
             assert rc == 101, (name, pack, rc, err)
             assert "panicked" in err

@@ -242,3 +242,73 @@ def test_text_feeder_inflates_bgzf_members_in_parallel(tmp_path):
     (tmp_path / "bad.fastq.gz").write_bytes(bytes(bad))
     with pytest.raises(hostlib.HostError):
         hostlib.text_feeder_walk(str(tmp_path / "bad.fastq.gz"), 1 << 16, 4)
+
+
+def _pack_host(seqs, L, reverse, o, recursion):
+    """sgc_pack_reads_host (the scalar packer of the C ABI) on a list of reads -> uint64 array [n, words]"""
+    import ctypes as C
+    import numpy as np
+    from sgcount_amd import _ffi
+    lib = _ffi.load()
+    flat = b"".join(seqs)
+    offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    np.cumsum([len(s) for s in seqs], out=offs[1:])
+    words = 2 if L > 23 else 1
+    out = np.zeros((len(seqs), words), dtype=np.uint64)
+    buf = (C.c_uint8 * max(len(flat), 1)).from_buffer_copy(flat or b"\0")
+    _ffi.check(lib.sgc_pack_reads_host(C.cast(buf, C.c_void_p), offs.ctypes.data, len(seqs), L, int(reverse), o, int(recursion),
+                                       out.ctypes.data))
+    return out
+
+
+def test_scanner_records_equal_the_host_packer(tmp_path):
+    """The scan path's record source (FastqScanner: memory-mapped text, blocks taken by several threads, line numbers chained
+    across blocks, SIMD fast path + sgc_pack_one) gives, for every read and in order, exactly the record of the scalar host
+    packer — both strands, recursion on/off, one- and two-word records, offsets 0/1/30, 'N' and lowercase bytes, short and
+    empty reads, lines that straddle blocks, CRLF terminators, no final newline, trailing blank lines."""
+    import random
+    import numpy as np
+    from sgcount_amd import hostlib
+    rng = random.Random(77)
+    seqs = []
+    for i in range(5000):
+        n = rng.choice([0, 1, 19, 20, 21, 22, 23, 40, 51, 52, 53, 60, 90, 150, 150, 150, 400])
+        alphabet = b"ACGT" if rng.random() < 0.8 else rng.choice([b"ACGTN", b"ACGTNacgtRY", b"ACGTJ"])
+        seqs.append(bytes(rng.choice(alphabet) for _ in range(n)))
+    seqs.append(b"ACGT" * 40_000)                                   # a line much longer than a block
+    def fastq(eol, final_newline=True, blank_tail=0):
+        out = []
+        for i, s in enumerate(seqs):
+            q = bytes(rng.choice(b"@+I#5") for _ in range(len(s)))
+            out.append(b"@r%d" % i + eol + s + eol + b"+" + eol + q + eol)
+        t = b"".join(out)
+        if not final_newline:
+            t = t[: -len(eol)]
+        return t + b"\n" * blank_tail
+    p = tmp_path / "r.fastq"
+    for eol, final_nl, tail in ((b"\n", True, 0), (b"\n", False, 0), (b"\r\n", True, 0), (b"\n", True, 3)):
+        p.write_bytes(fastq(eol, final_nl, tail))
+        for L, rev, o, rec in ((20, False, 30, True), (20, True, 30, True), (20, False, 0, True), (20, True, 1, False),
+                               (23, False, 5, True), (24, True, 7, True), (30, False, 30, False), (4, False, 2, True)):
+            want = _pack_host(seqs, L, rev, o, rec)
+            for threads, block in ((1, 1 << 22), (3, 4096), (4, 1 << 16)):
+                got, lines = hostlib.scan_records(str(p), L, rev, o, rec, threads=threads, block_bytes=block)
+                assert lines == 4 * len(seqs)
+                assert got.shape == want.shape and np.array_equal(got, want), (eol, final_nl, tail, L, rev, o, rec, threads, block)
+    # the scanner declines what is not plain FASTQ text; malformed and truncated records panic (exit code 101)
+    (tmp_path / "lib.fa").write_bytes(b">a\nACGT\n")
+    assert hostlib.scan_records(str(tmp_path / "lib.fa"), 4) is None
+    (tmp_path / "empty.fastq").write_bytes(b"")
+    assert hostlib.scan_records(str(tmp_path / "empty.fastq"), 4) is None
+    good = fastq(b"\n")
+    lines = good.split(b"\n")
+    bad = list(lines)
+    bad[4 * 700 + 2] = b"-"
+    (tmp_path / "bad.fastq").write_bytes(b"\n".join(bad))
+    with pytest.raises(hostlib.HostError) as e:
+        hostlib.scan_records(str(tmp_path / "bad.fastq"), 20, threads=3, block_bytes=4096)
+    assert e.value.code == 101 and "line %d " % (4 * 700 + 3) in str(e.value)
+    (tmp_path / "trunc.fastq").write_bytes(b"\n".join(lines[: 4 * 900 + 2]) + b"\n")
+    with pytest.raises(hostlib.HostError) as e:
+        hostlib.scan_records(str(tmp_path / "trunc.fastq"), 20, threads=2, block_bytes=8192)
+    assert e.value.code == 101 and "truncated" in str(e.value)

@@ -391,3 +391,47 @@ def test_device_resident_push_and_accumulation(S):
     assert one == run([1, 64, 65, 10000, 29999])
     want, tot, mat = O.count_text(_fasta(guides), _reads_fasta(reads), False, 4, False, True)
     assert one == (want, tot, mat)
+
+
+def test_async_packed_pushes_are_batched_on_the_device(S):
+    """sgc_sample_push_packed_async: records pushed from pinned host memory in many small pieces are uploaded on the upload
+    stream into two alternating device batch buffers and counted one batch at a time — same table as ONE synchronous push,
+    whatever the batch size (smaller than a push, not a multiple of it, larger than everything), across a sample reset, and
+    with a finish in the middle of a batch."""
+    import ctypes as C
+    rng = random.Random(11)
+    guides, reads = _random_case(rng, 20, 400, 50000, 4)
+    lib = _lib(S, _fasta(guides))
+    dev = lib.device(True)
+    ffi, L = S._ffi, dev.lib
+    recs = S.pack_reads_host(reads, 20, S.Offset.Forward(4), True)
+    n = len(reads)
+    pinned = L.sgc_alloc_pinned(n * 8)
+    assert pinned
+    C.memmove(pinned, recs.ctypes.data, n * 8)
+    want, tot, mat = O.count_text(_fasta(guides), _reads_fasta(reads), False, 4, False, True)
+
+    def finish(smp):
+        out = np.zeros(len(guides), dtype=np.uint64)
+        t, m = C.c_uint64(), C.c_uint64()
+        ffi.check(L.sgc_sample_finish(smp, out.ctypes.data, C.byref(t), C.byref(m)))
+        return out.tolist(), t.value, m.value
+
+    try:
+        for batch, piece in ((1000, 333), (4096, 4096), (7, 50000), (1 << 20, 1234), (20000, 20000)):
+            ffi.check(L.sgc_set_option(dev.ctx, b"batch_records", batch))
+            smp = C.c_void_p()
+            ffi.check(L.sgc_sample_begin(dev.ctx, C.byref(smp), 0, 4, 1))
+            for rep in range(2):                                   # the second round after a reset: the batch state starts over
+                for a in range(0, n, piece):
+                    m = min(piece, n - a)
+                    ffi.check(L.sgc_sample_push_packed_async(smp, pinned + 8 * a, m))
+                    if a == piece * 3:
+                        assert finish(smp)[1] == a + m             # a finish in the middle of a batch counts what was pushed so far
+                ffi.check(L.sgc_sample_wait_uploads(smp, 0))
+                assert finish(smp) == (want, tot, mat), (batch, piece, rep)
+                ffi.check(L.sgc_sample_reset(smp))
+            L.sgc_sample_free(smp)
+    finally:
+        ffi.check(L.sgc_set_option(dev.ctx, b"batch_records", 1 << 24))
+        L.sgc_free_pinned(pinned)

@@ -19,6 +19,8 @@ for rep in range(3):
         ctx = C.c_void_p()
         t0 = time.perf_counter()
         _ffi.check(lib.sgc_init(0, C.byref(ctx)))
+        if rep == 2:
+            _ffi.check(lib.sgc_set_option(ctx, b"verbose", 1))
         t1 = time.perf_counter()
         _ffi.check(lib.sgc_set_library(ctx, flat, 100_000, 20, one_mm))
         t2 = time.perf_counter()
