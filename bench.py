@@ -506,6 +506,47 @@ def main():
     counts, total, matched = wl.result(rows[(args.steps - 1) % rows.shape[0]])
     assert total == args.reads and int(counts.sum()) == matched, "count-sum invariant violated"
 
+    # Placement trials (sgc_set_option "place_trials", OFF by default in the library and in `value` above): a host that
+    # re-counts resident samples on one ctx — this loop is one — may let the first large pass try several placements of its
+    # block pool and keep the fastest.  Priced separately: the same K steps again with the trials on, their one-off cost,
+    # and the memory they held meanwhile.
+    placement = None
+    if args.reads >= (1 << 25):
+        import ctypes as C
+        wl.dl.set_option("place_trials", 32)
+        fence()
+        t1 = time.perf_counter()
+        step(0)                                   # this pass runs the search
+        fence()
+        first_ms = (time.perf_counter() - t1) * 1e3
+        for i in range(max(args.warmup - 1, 0)):
+            step(i)
+        fence()
+        wl.dl.timing(True)
+        wl.dl.timing(reset=True)
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        fence()
+        el2 = time.perf_counter() - t1
+        tm2 = wl.dl.timing(reset=True)
+        wl.dl.timing(False)
+        if world > 1:
+            tmax = torch.tensor([el2], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el2 = float(tmax.item())
+        info = (C.c_uint64 * 4)()
+        wl.abi.sgc_placement_info(wl.dl.ctx, info)
+        c2, t2, m2 = wl.result(rows[(args.steps - 1) % rows.shape[0]])
+        assert t2 == total and m2 == matched and bool((c2 == counts).all()), "placement trials changed the table"
+        placement = {"value_with_placement_trials": world * args.reads * args.steps / el2, "ms_per_step": 1e3 * el2 / args.steps,
+                     "kernel_ms_per_step": (tm2.part_ms + tm2.lookup_ms + tm2.miss_ms + tm2.hist_ms) / args.steps,
+                     "search": {"candidates": int(info[0]), "transient_bytes": int(info[1]), "search_ms": int(info[2]) / 1e3,
+                                "kept": int(info[3]), "first_pass_wall_ms": first_ms},
+                     "note": "not part of `value`: the exchange is left out of this second timed region; the search is paid once per ctx "
+                             "and is worth it only to a host that re-counts resident samples of >= 32M records"}
+        wl.dl.set_option("place_trials", 1)
+
     out = {
         "metric": "reads/s", "value": world * args.reads * args.steps / elapsed, "unit": "reads/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
@@ -522,6 +563,8 @@ def main():
     }
     if exch:
         out["exchange"] = exch
+    if placement:
+        out["placement_trials"] = placement
     if rank == 0:
         reads_timed = args.reads * args.steps
         # the count path is a short pipeline of kernels over the same reads; the roofline is

@@ -199,14 +199,18 @@ void sgc_free_pinned(void *p);
 /* Tuning knobs (all results-preserving): "variant" (count path variant 0..4; default 4), "max_chunk"
  * (records per internal pass), "k1_wgs" (workgroups of the partition kernel), "per_lane" (variant 2), "host_build" /
  * "perm_bloom_bits" (how the next sgc_set_library builds the single-mismatch table and its filter), "force_bytes" (the next
- * sgc_set_library uses the byte-string path even for a library the packed path could serve), "place_trials" (1..64, default 32:
+ * sgc_set_library uses the byte-string path even for a library the packed path could serve), "place_trials" (1..64, default 1 = off:
  * where the block pool of a large pass — 32M records or more — falls in device memory decides whether its partition and
- * slice-count kernels run ~10 % faster or slower, so the first such pass allocates up to that many candidate pools (all held at once:
- * ~1 GB each for 100M records), times the partition kernel on each (under 1 ms each; it stops at a candidate 11 % ahead of the slowest
- * seen, or when memory runs short) and keeps the fastest; 1 = take what hipMalloc gives), "verbose" (diagnostics on stderr).  No environment
+ * slice-count kernels run up to ~8 % faster or slower, so a host that counts many resident samples of that size on one ctx may
+ * opt in: the first such pass then allocates up to that many candidate pools — all held at once, ~1 GB each for 100M records,
+ * never more than a quarter of the device memory that is free at that moment —, times the partition kernel on each (under 1 ms
+ * each; it stops at a candidate 11 % ahead of the slowest seen) and keeps the fastest: 10-30 ms once per ctx, which a single
+ * sample never earns back; sgc_placement_info reports what the search did), "batch_records" (records per device-side batch of
+ * sgc_sample_push_packed_async), "verbose" (diagnostics on stderr).  No environment
  * variable changes what the library computes or which kernels it runs.  "dbg" sets
- * timing-only ablation flags of the kernels — results are WRONG while it is non-zero, so it is refused unless
- * SGC_ALLOW_DBG=1 is in the environment (tools/tune.py sets it). */
+ * timing-only ablation flags / phase stamps of the kernels: they are compiled out of the shipped library, which refuses
+ * a non-zero value (a profiling build — SGC_HIPCC_FLAGS=-DSGC_ABLATE=1 or -DSGC_STAMPS=1 — accepts it; results are
+ * WRONG while an ablation is on). */
 int sgc_set_option(sgc_ctx *, const char *key, int64_t value);
 
 /* ---- diagnostics -------------------------------------------------------------------------------- */
@@ -215,6 +219,9 @@ int sgc_set_option(sgc_ctx *, const char *key, int64_t value);
  * library of arbitrary bytes / L > 30 — the byte-string table.  stats[4]: [0] = 1 packed path, 2 byte-string path;
  * [1] = library slots; [2] = single-mismatch entries (0 unless enable_1mm); [3] = 1 if the two-choice image was built. */
 int sgc_check_host_tables(const uint8_t *seqs, uint32_t n, uint32_t L, int enable_1mm, uint64_t *stats);
+/* What the last placement search of the ctx did ("place_trials"): out4 = {candidate pools tried, peak transient bytes held
+ * beyond the one kept, duration in microseconds, index of the candidate kept}; all zero if none ran. */
+int sgc_placement_info(sgc_ctx *, uint64_t *out4);
 int sgc_timing_enable(sgc_ctx *, int on);     /* record HIP events around every kernel (adds a sync at read) */
 int sgc_timing_read(sgc_ctx *, sgc_timing *out, int reset);
 const char *sgc_last_error(void);

@@ -61,6 +61,7 @@ SYMBOLS = {
     "sgc_free_pinned": (None, [_vp]),
     "sgc_set_option": (_i, [_vp, C.c_char_p, C.c_int64]),
     "sgc_check_host_tables": (_i, [_u8p, _u32, _u32, _i, _vp]),
+    "sgc_placement_info": (_i, [_vp, _vp]),
     "sgc_timing_enable": (_i, [_vp, _i]),
     "sgc_timing_read": (_i, [_vp, C.POINTER(Timing), _i]),
     "sgc_last_error": (C.c_char_p, []),

@@ -391,7 +391,30 @@ TextFeeder::TextFeeder(const std::string &path_, size_t slice_bytes, size_t ring
         if (pread(fd, hd, 18, 0) == 18 && hd[2] == 8 && (hd[3] & 4) && hd[10] + 256u * hd[11] >= 6 && hd[12] == 'B' && hd[13] == 'C' && hd[14] == 2 && hd[15] == 0 &&
             file_size >= 28) {
             void *m = mmap(nullptr, file_size, PROT_READ, MAP_PRIVATE, fd, 0);
-            if (m != MAP_FAILED) { map = (const uint8_t *)m; is_bgzf = true; madvise(m, file_size, MADV_SEQUENTIAL); }
+            if (m != MAP_FAILED) {
+                // BGZF only if EVERY member announces its size (bgzip output concatenated with ordinary gzip output is legal
+                // gzip, and zlib — like the reference's flate2 — reads it): hop through the member headers once; anything
+                // else takes the sequential inflater below
+                const uint8_t *mp = (const uint8_t *)m;
+                size_t off = 0;
+                bool chain = true;
+                while (chain && off < file_size) {
+                    const uint8_t *h = mp + off;
+                    if (file_size - off < 28 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { chain = false; break; }
+                    const size_t xlen = h[10] + 256u * h[11];
+                    if (12 + xlen + 8 > file_size - off) { chain = false; break; }
+                    size_t bsize = 0;
+                    for (size_t x = 12; x + 4 <= 12 + xlen;) {
+                        const size_t slen = h[x + 2] + 256u * h[x + 3];
+                        if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2 && x + 6 <= 12 + xlen) bsize = (size_t)(h[x + 4] + 256u * h[x + 5]) + 1;
+                        x += 4 + slen;
+                    }
+                    if (bsize < 12 + xlen + 8 || bsize > file_size - off) chain = false;
+                    else off += bsize;
+                }
+                if (chain) { map = mp; is_bgzf = true; madvise(m, file_size, MADV_SEQUENTIAL); }
+                else munmap(m, file_size);
+            }
         }
     }
     if (is_bgzf) {
@@ -673,7 +696,12 @@ static bool count_fastq_text(sgc_sample *smp, const std::string &path, const Cou
             const void *nl = len ? memrchr(data, '\n', len) : nullptr;
             const size_t keep = nl ? (size_t)((const uint8_t *)nl - part) + 1 : 0;
             tail = part_len - keep;
-            if (tail > TextFeeder::HEAD) throw Error("FASTQ line longer than " + std::to_string(TextFeeder::HEAD) + " bytes in " + path);
+            if (tail > TextFeeder::HEAD) {
+                // the carry area in front of a slice holds one unfinished line of up to HEAD bytes; with nothing pushed yet the
+                // record reader (no line limit, like fxread) can still take the whole sample
+                if (first_line == 0) return false;
+                throw Error("FASTQ line longer than " + std::to_string(TextFeeder::HEAD) + " bytes in " + path + " (--pack device reads lines of any length)");
+            }
             memcpy(feed.buffer_of(k + 1) + TextFeeder::HEAD - tail, part + keep, tail);
             part_len = keep;
         } else {

@@ -130,7 +130,7 @@ struct SampleStats {                    // where one sample's wall time went (ho
 // slice before.
 class TextFeeder {
   public:
-    static constexpr size_t HEAD = 1u << 20;
+    static constexpr size_t HEAD = 4u << 20;      // longest unfinished line that can be carried from one slice to the next
     // threads: readers of a plain file; inflate_threads (>= threads is used): inflaters of a BGZF file
     TextFeeder(const std::string &path, size_t slice_bytes, size_t ring, size_t threads, void *(*alloc)(size_t),
                void (*release)(void *), size_t inflate_threads = 0);

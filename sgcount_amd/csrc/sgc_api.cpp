@@ -11,6 +11,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <utility>
@@ -22,6 +24,12 @@
 #include "sgc_kernels.h"
 #include "sgc_runs.h"
 #include "sgc_tables.h"
+
+#if defined(SGC_STAMPS) && SGC_STAMPS
+#define SGC_STAMPS_BUILD 1
+#else
+#define SGC_STAMPS_BUILD 0
+#endif
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -50,7 +58,12 @@ struct sgc_ctx {
     // Placement trials (DESIGN.md §6 "the two regimes of the pass"): where the pool falls in memory decides whether K1 and K2
     // run in their fast or their slow regime (~10 % apart), so the first large pass tries a few placements and keeps the fastest
     bool verbose = false;              // diagnostics on stderr (option "verbose")
-    int place_trials = 32;             // allocations tried (1 = take what hipMalloc gives)
+    size_t vmm_chunk = 0;              // experiment: physical chunk size of the block pool (see vmm_alloc above); 0 = plain hipMalloc
+    uint64_t vmm_shuffle = 0;          // map the pool's chunks in a seeded random order (0 = as created)
+    bool vmm_runs = false;             // ... the run buffers of the core passes too (they are read more than written: plain memory reads faster)
+    int place_trials = 1;              // allocations tried (1 = take what hipMalloc gives: the default; a host that re-counts resident
+                                       // samples of >= 32M records may opt in — the search costs 10-30 ms and holds extra pools meanwhile)
+    uint64_t place_info[4] = {0, 0, 0, 0};   // last search: candidates tried, peak transient bytes, duration in us, index of the one kept
     void *placed_pool = nullptr;       // the pool the trials chose (they run again if it was re-allocated since)
     bool six_byte = true;              // ... and the slice blocks hold six-byte records (needs direct, L <= 21)
     bool tag_sub = true;               // K1 tags the pass-A partition inside the slice, K2 counts misses by it (no histogram sweep)
@@ -97,7 +110,7 @@ struct sgc_ctx {
     int variant = 4;            // count path variant: 0 direct atomics, 1/2 gid array + LDS histogram,
                                 // 3 partitioned + probing miss resolver, 4 partitioned + in-LDS core resolver
     int per_lane = 4;           // records per lane in the v2 lookup kernel
-    uint32_t dbg = 0;           // timing-only ablation flags (results are wrong when non-zero)
+    uint32_t dbg = 0;           // timing-only ablation flags / phase stamps (only in -DSGC_ABLATE=1 / -DSGC_STAMPS=1 builds; results are wrong when an ablation is on)
     uint32_t k1_wgs = 512;      // workgroups of the partition kernel: two per CU (more leave more half-empty blocks open, fewer expose its phases)
     uint64_t max_chunk = 1ull << 27;   // records per internal pass (bounds the scratch buffers)
     uint64_t batch_records = 1ull << 24;   // sgc_sample_push_packed_async: records per device-side batch (one count pass each)
@@ -135,10 +148,89 @@ struct sgc_sample {
 
 // ---- helpers -------------------------------------------------------------------------------------
 
-static int ensure(void **p, size_t *cap, size_t need) {
+// Experiment hook (option "vmm_chunk_mb", default 0 = plain hipMalloc): the block pool built with the virtual-memory API — a
+// reserved address range backed by physical chunks of `chunk` bytes (hipMemCreate / hipMemMap), optionally mapped in a shuffled
+// order.  Why it exists: WHERE the pool lies in physical memory decides whether k_partition / k_count_slices run in their fast
+// or their slow regime.  What round 3 learnt with it (tools/ubench/contig_bw.hip, tools/regime_sweep.py): a
+// physically contiguous pool (hipDeviceMallocContiguous) is the SLOWEST placement (K1 0.39-0.42 ms against 0.30-0.35); plain
+// streaming kernels write chunked memory faster than hipMalloc'ed memory (6.4 against 4.4 TB/s) and read it slower (6.3
+// against 7.1); but for the pass neither the chunk size nor the mapping order removes the spread — the k-th allocation of a
+// process lands in the same regime in the next process, whichever API made it: the regime is a property of the physical
+// region, not of the mapping.
+struct vmm_rec { size_t bytes; std::vector<hipMemGenericAllocationHandle_t> handles; };
+static std::mutex g_vmm_mu;
+static std::map<void *, vmm_rec> g_vmm;            // address -> its chunks (all contexts of the process)
+
+static void dev_free(void *p) {
+    if (!p) return;
+    vmm_rec r;
+    {
+        std::lock_guard<std::mutex> lk(g_vmm_mu);
+        auto it = g_vmm.find(p);
+        if (it == g_vmm.end()) { (void)hipFree(p); return; }
+        r = std::move(it->second);
+        g_vmm.erase(it);
+    }
+    (void)hipMemUnmap(p, r.bytes);
+    for (auto h : r.handles) (void)hipMemRelease(h);
+    (void)hipMemAddressFree(p, r.bytes);
+}
+
+static bool vmm_alloc(int device, void **out, size_t bytes, size_t chunk, uint64_t shuffle = 0) {
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) { (void)hipGetLastError(); return false; }
+    chunk = (std::max(chunk, gran) + gran - 1) / gran * gran;
+    const size_t total = (bytes + chunk - 1) / chunk * chunk, n = total / chunk;
+    void *va = nullptr;
+    if (hipMemAddressReserve(&va, total, 0, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+    vmm_rec r; r.bytes = total;
+    bool ok = true;
+    size_t mapped = 0;
+    for (size_t i = 0; i < n && ok; i++) {
+        hipMemGenericAllocationHandle_t h;
+        ok = hipMemCreate(&h, chunk, &prop, 0) == hipSuccess;
+        if (ok) r.handles.push_back(h);
+    }
+    if (ok && shuffle) {            // the chunks in a seeded random order (xorshift Fisher-Yates)
+        uint64_t x = shuffle * 0x9E3779B97F4A7C15ull + 1;
+        for (size_t i = n; i > 1; i--) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            std::swap(r.handles[i - 1], r.handles[x % i]);
+        }
+    }
+    for (size_t i = 0; i < n && ok; i++) {
+        ok = hipMemMap((char *)va + i * chunk, chunk, 0, r.handles[i], 0) == hipSuccess;
+        if (ok) mapped = (i + 1) * chunk;
+    }
+    hipMemAccessDesc ad = {};
+    ad.location = prop.location; ad.flags = hipMemAccessFlagsProtReadWrite;
+    ok = ok && hipMemSetAccess(va, total, &ad, 1) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        if (mapped) (void)hipMemUnmap(va, mapped);
+        for (auto h : r.handles) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(va, total);
+        return false;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_vmm_mu);
+        g_vmm[va] = std::move(r);
+    }
+    *out = va;
+    return true;
+}
+
+// vmm_chunk != 0: build the buffer from physical chunks of that size (falls back to hipMalloc if the device refuses)
+static int ensure(void **p, size_t *cap, size_t need, int device = 0, size_t vmm_chunk = 0, uint64_t shuffle = 0) {
     if (need <= *cap) return SGC_OK;
     const size_t want = std::max(need, *cap * 2);
-    if (*p) { HIP_TRY(hipFree(*p)); *p = nullptr; *cap = 0; }
+    if (*p) { dev_free(*p); *p = nullptr; *cap = 0; }
+    if (vmm_chunk == 1024) {         // experiment ("vmm_chunk_kb" = 1): physically contiguous
+        if (hipExtMallocWithFlags(p, want, hipDeviceMallocContiguous) == hipSuccess) { *cap = want; return SGC_OK; }
+        (void)hipGetLastError(); *p = nullptr;
+    } else if (vmm_chunk && vmm_alloc(device, p, want, vmm_chunk, shuffle)) { *cap = want; return SGC_OK; }
     HIP_TRY(hipMalloc(p, want));
     *cap = want;
     return SGC_OK;
@@ -203,7 +295,7 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
         if (c->variant >= 3 && sgc_part_supported(c->v_lib, c->rec16)) {
             sgc_part_geometry g;
             sgc_part_plan(chunk, c->v_lib, c->k1_wgs, &g);
-            int rc = ensure(&c->d_pool, &c->pool_cap, g.pool_bytes);
+            int rc = ensure(&c->d_pool, &c->pool_cap, g.pool_bytes, c->device, c->vmm_chunk, c->vmm_shuffle);
             if (rc) return rc;
             rc = ensure(&c->d_desc, &c->desc_cap, g.desc_bytes);
             if (rc) return rc;
@@ -227,7 +319,7 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
                 sgc_core_geometry cg;
                 sgc_core_plan(chunk, c->v_core[0], c->v_core[1], sgc_part_k2_grid(g) + (direct ? sgc_part_k2_shares(g) : 0u), &cg);
                 const size_t mrun_bytes = c->dense ? (size_t)g.pool_bytes << (direct ? (uint32_t)sub : 0u) : 0;
-                rc = ensure(&c->d_cbuf, &c->cbuf_cap, (size_t)(cg.runs_a_bytes + mrun_bytes + cg.fwd_bytes));
+                rc = ensure(&c->d_cbuf, &c->cbuf_cap, (size_t)(cg.runs_a_bytes + mrun_bytes + cg.fwd_bytes), c->device, c->vmm_runs ? c->vmm_chunk : 0);
                 if (rc) return rc;
                 rc = ensure(&c->d_csmall, &c->csmall_cap, cg.small_bytes);
                 if (rc) return rc;
@@ -239,13 +331,19 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
                     struct cand { void *pool; float ms; };
                     std::vector<cand> cands;
                     cands.push_back({c->d_pool, 0.f});
+                    const auto search_t0 = std::chrono::steady_clock::now();
+                    // the candidates are all held at once: never more than a quarter of the memory that is free right now
+                    size_t mem_free = 0, mem_total = 0;
+                    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) { (void)hipGetLastError(); mem_free = 0; }
+                    const int max_extra = (int)std::min<size_t>((size_t)c->place_trials - 1, (mem_free / 4) / std::max<size_t>(c->pool_cap, 1));
                     hipEvent_t e0 = nullptr, e1 = nullptr;
                     bool ok = hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
                     float worst = 0.f;
-                    for (int k = 0; ok && k < c->place_trials; k++) {
+                    for (int k = 0; ok && k <= max_extra; k++) {
                         if (k) {
                             void *P = nullptr;
-                            if (hipMalloc(&P, c->pool_cap) != hipSuccess) { (void)hipGetLastError(); break; }    // out of memory: settle for what there is
+                            size_t cap2 = 0;
+                            if (ensure(&P, &cap2, c->pool_cap, c->device, c->vmm_chunk) != SGC_OK) { (void)hipGetLastError(); break; }    // out of memory: settle for what there is
                             cands.push_back({P, 0.f});
                         }
                         cand &cd = cands.back();
@@ -267,9 +365,14 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
                     for (size_t k = 1; k < cands.size(); k++)
                         if (ok && cands[k].ms > 0.f && cands[k].ms < cands[best].ms) best = k;
                     for (size_t k = 0; k < cands.size(); k++)
-                        if (k != best) hipFree(cands[k].pool);
+                        if (k != best) dev_free(cands[k].pool);
                     c->d_pool = cands[best].pool;
                     c->placed_pool = c->d_pool;
+                    c->place_info[0] = cands.size(); c->place_info[1] = (uint64_t)(cands.size() - 1) * c->pool_cap;
+                    c->place_info[2] = (uint64_t)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - search_t0).count();
+                    c->place_info[3] = best;
+                    if (c->verbose) fprintf(stderr, "placement trials: %zu candidates (%.2f GB held meanwhile), kept #%zu, %.1f ms\n", cands.size(),
+                                            (double)c->place_info[1] / 1e9, best, (double)c->place_info[2] / 1e3);
                     pool = (uint64_t *)c->d_pool;
                     HIP_TRY(hipGetLastError());
                     // the real pass starts over on the chosen pool
@@ -450,17 +553,17 @@ void sgc_free(sgc_ctx *c) {
     timing_drain(c);
     for (auto e : c->free_events) hipEventDestroy(e);
     free_tables(c);
-    if (c->d_stage) hipFree(c->d_stage);
-    if (c->d_aux) hipFree(c->d_aux);
-    if (c->d_recs) hipFree(c->d_recs);
-    if (c->d_gids) hipFree(c->d_gids);
-    if (c->d_pool) hipFree(c->d_pool);
-    if (c->d_desc) hipFree(c->d_desc);
-    if (c->d_cbuf) hipFree(c->d_cbuf);
-    if (c->d_csmall) hipFree(c->d_csmall);
+    dev_free(c->d_stage);
+    dev_free(c->d_aux);
+    dev_free(c->d_recs);
+    dev_free(c->d_gids);
+    dev_free(c->d_pool);
+    dev_free(c->d_desc);
+    dev_free(c->d_cbuf);
+    dev_free(c->d_csmall);
     if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
     if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
-    for (int i = 0; i < 2; i++) { if (c->d_text[i]) hipFree(c->d_text[i]); if (c->ev_use[i]) hipEventDestroy(c->ev_use[i]); }
+    for (int i = 0; i < 2; i++) { dev_free(c->d_text[i]); if (c->ev_use[i]) hipEventDestroy(c->ev_use[i]); }
     for (int i = 0; i < sgc_ctx::UP_RING; i++) if (c->ev_up[i]) hipEventDestroy(c->ev_up[i]);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
@@ -490,8 +593,9 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
     if (!c || !key) return fail(SGC_E_ARG, "sgc_set_option: NULL argument");
     if (!strcmp(key, "variant")) { c->variant = (int)value; return SGC_OK; }
     if (!strcmp(key, "dbg")) {
-        // timing-only ablation flags of the kernels (results are WRONG when non-zero): profiling tools opt in
-        if (value && !getenv("SGC_ALLOW_DBG")) return fail(SGC_E_ARG, "sgc_set_option: dbg flags need SGC_ALLOW_DBG=1 in the environment");
+        // timing-only ablation flags / phase stamps of the kernels: they exist only in a library built for it (sgc_kernels.h)
+        if (value && !(SGC_ABLATE || SGC_STAMPS_BUILD))
+            return fail(SGC_E_ARG, "sgc_set_option: dbg flags need a library built with -DSGC_ABLATE=1 or -DSGC_STAMPS=1 (SGC_HIPCC_FLAGS; tools/tune.py --ablate)");
         c->dbg = (uint32_t)value; return SGC_OK;
     }
     if (!strcmp(key, "k1_wgs")) { c->k1_wgs = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 65536)); return SGC_OK; }
@@ -517,6 +621,20 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
         c->perm_bloom_bits = (uint32_t)value; return SGC_OK;
     }
     if (!strcmp(key, "verbose")) { c->verbose = value != 0; return SGC_OK; }
+    if (!strcmp(key, "vmm_chunk_mb")) {          // takes effect when the buffers are next (re)allocated
+        if (value < 0 || value > 1024) return fail(SGC_E_ARG, "vmm_chunk_mb must be 0 (plain hipMalloc) .. 1024");
+        c->vmm_chunk = (size_t)value << 20; return SGC_OK;
+    }
+    if (!strcmp(key, "vmm_runs")) { c->vmm_runs = value != 0; return SGC_OK; }
+    if (!strcmp(key, "vmm_shuffle")) { c->vmm_shuffle = (uint64_t)value; return SGC_OK; }
+    if (!strcmp(key, "vmm_chunk_kb")) { c->vmm_chunk = (size_t)value << 10; return SGC_OK; }       // experiments (1 KB = physically contiguous)
+    if (!strcmp(key, "drop_scratch")) {          // frees the pass scratch: the next pass allocates it afresh (with the options of that moment)
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        dev_free(c->d_pool); c->d_pool = nullptr; c->pool_cap = 0; c->placed_pool = nullptr;
+        dev_free(c->d_cbuf); c->d_cbuf = nullptr; c->cbuf_cap = 0;
+        return SGC_OK;
+    }
     if (!strcmp(key, "place_trials")) {
         if (value < 1 || value > 64) return fail(SGC_E_ARG, "place_trials must be 1..64");
         c->place_trials = (int)value; c->placed_pool = nullptr;
@@ -713,6 +831,8 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
                     e = hipMalloc((void **)&c->d_amb, amb.size() * 8);
                     if (e == hipSuccess) e = hipMemcpyAsync(c->d_amb, amb.data(), amb.size() * 8, hipMemcpyHostToDevice, c->stream);
                 }
+                if (e == hipSuccess && enable_1mm && c->d_amb)
+                    for (int k = 0; k < 2; k++) sgc_flag_ambiguous(c->stream, c->d_core_gids[k], hc[k].gids.size(), c->d_amb);
                 // the host vectors above must outlive the copies: synchronise before they go out of scope, error or not
                 const hipError_t e2 = hipStreamSynchronize(c->stream);
                 if (e == hipSuccess) e = e2;
@@ -1207,6 +1327,12 @@ int sgc_check_host_tables(const uint8_t *seqs, uint32_t n, uint32_t L, int enabl
         sgc_build_permute_table(keys, L, h, hp, nullptr, nullptr);
         stats[2] = hp.entries;
     }
+    return SGC_OK;
+}
+
+int sgc_placement_info(sgc_ctx *c, uint64_t *out4) {
+    if (!c || !out4) return fail(SGC_E_ARG, "sgc_placement_info: NULL");
+    memcpy(out4, c->place_info, sizeof(c->place_info));
     return SGC_OK;
 }
 

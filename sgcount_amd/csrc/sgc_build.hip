@@ -92,3 +92,21 @@ int sgc_device_build_permute(hipStream_t st, const uint64_t *d_keys, uint32_t n,
                        log2_slots, gid_bits, d_bloom, bloom_log2, (unsigned long long *)d_amb, d_entries);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// Marks, in a core index's guide ids, the guides that have an ambiguous child (any bit of their mask set): bit 31 of the id.
+// k_core reads the id from LDS anyway and gathers a guide's mask from global memory only when that bit is set — a few
+// hundred guides of 100k have a neighbour within two substitutions.
+__global__ void __launch_bounds__(256) k_flag_ambiguous(uint32_t *__restrict__ gids, uint64_t n_entries, const ulonglong2 *__restrict__ amb) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_entries) return;
+    const uint32_t g = gids[i];
+    if (g == SGC_NONE) return;
+    const ulonglong2 m = amb[g];
+    if (m.x | m.y) gids[i] = g | 0x80000000u;
+}
+
+void sgc_flag_ambiguous(hipStream_t st, uint32_t *d_gids, uint64_t n_entries, const uint64_t *d_amb) {
+    if (!n_entries) return;
+    hipLaunchKernelGGL(k_flag_ambiguous, dim3((unsigned)((n_entries + 255) / 256)), dim3(256), 0, st, d_gids, n_entries,
+                       reinterpret_cast<const ulonglong2 *>(d_amb));
+}

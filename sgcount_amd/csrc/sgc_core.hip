@@ -117,10 +117,10 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
         const uint32_t p = find_extent<SGC_CORE_MAX_LOG2_P>(cs_, P, ch);
         if (p != cur_p) {                                    // uniform over the workgroup
             __syncthreads();
-            if (cur_p != 0xFFFFFFFFu && !(dbg & 8192))
+            if (cur_p != 0xFFFFFFFFu && !SGC_DBG(dbg, 8192u))
                 for (uint32_t i = t; i < SGC_CORE_EMAX; i += KC_THREADS) {
                     const uint32_t v = cnt[i];
-                    if (v) atomicAdd(&counts[tgid[i]], v);
+                    if (v) atomicAdd(&counts[tgid[i] & 0x7FFFFFFFu], v);
                 }
             __syncthreads();
             const uint64_t *ge = cv.ents + (size_t)p * SGC_CORE_EMAX;
@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             uint32_t cc = 0;                                              // visible distance-1 guides, 8 bits per window
             uint32_t k0 = 0, k1 = 0, k2 = 0;                              // entry of the (last) one
             uint32_t d0 = 0, d1 = 0, d2 = 0;                              // its differing base (one bit of the rest)
-            if (vis && !(dbg & 1024)) {
+            if (vis && !SGC_DBG(dbg, 1024u)) {
                 const uint32_t b = sgc_core_home(sgc_core_hash(corev), cv.log2_p);
                 const uint32_t e_end = start[b + 1];
                 for (uint32_t i = start[b]; i < e_end; i++) {
@@ -247,7 +247,11 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 const uint32_t ll = lvl == 1 ? ll1 : (lvl == 3 ? ll2 : ll0);
                 const uint32_t jr = (uint32_t)__builtin_ctz(dm) >> 1, j = jr < ll ? jr : jr + cl;
                 const uint32_t bit = 4 * j + ((Ra >> (2 * jr)) & 3u);
-                const ulonglong2 mk = (dbg & 2048) ? make_ulonglong2(0, 0) : amb[tgid[k]];
+                // bit 31 of the staged guide id: "some child of this guide has another parent" (sgc_flag_ambiguous: a couple of
+                // hundred of 100k guides) — only then is the guide's mask worth a gather from global memory
+                const uint32_t tg = tgid[k];
+                if (!(tg >> 31) || SGC_DBG(dbg, 2048u)) break;
+                const ulonglong2 mk = amb[tg & 0x7FFFFFFFu];
                 if (!(((bit < 64 ? mk.x : mk.y) >> (bit & 63)) & 1ull)) break;
                 lm &= lm - 1u;                   // ambiguous child: this level fails, on to the next
                 lvl = 6; res = SGC_NONE;
@@ -258,9 +262,15 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 // inside the core either ('N' inside the core — unk — stays undecided)
                 const uint32_t cand = unk_above & ~(((unk & 2u) ? 2u : 0u) | ((unk & 4u) ? 8u : 0u) | ((unk & 1u) ? 32u : 0u));
                 const uint32_t fw = 1u << (cv.filt_log2 - 5);
-                if (cand & 2u) { const uint32_t x = sgc_rest_hash(R1, cv.filt_log2); if (!((cv.filt[fw + (x >> 5)] >> (x & 31u)) & 1u)) unk_above &= ~2u; }
-                if (cand & 8u) { const uint32_t x = sgc_rest_hash(R2, cv.filt_log2); if (!((cv.filt[2u * fw + (x >> 5)] >> (x & 31u)) & 1u)) unk_above &= ~8u; }
-                if (cand & 32u) { const uint32_t x = sgc_rest_hash(R0, cv.filt_log2); if (!((cv.filt[x >> 5] >> (x & 31u)) & 1u)) unk_above &= ~32u; }
+                // the (up to) three words are requested together — one round trip to the L2, not three in a row; a lane
+                // without that candidate reads word 0
+                const uint32_t x1 = sgc_rest_hash(R1, cv.filt_log2), x2 = sgc_rest_hash(R2, cv.filt_log2), x0 = sgc_rest_hash(R0, cv.filt_log2);
+                const uint32_t w1 = cv.filt[(cand & 2u) ? fw + (x1 >> 5) : 0u];
+                const uint32_t w2 = cv.filt[(cand & 8u) ? 2u * fw + (x2 >> 5) : 0u];
+                const uint32_t w0 = cv.filt[(cand & 32u) ? (x0 >> 5) : 0u];
+                if ((cand & 2u) && !((w1 >> (x1 & 31u)) & 1u)) unk_above &= ~2u;
+                if ((cand & 8u) && !((w2 >> (x2 & 31u)) & 1u)) unk_above &= ~8u;
+                if ((cand & 32u) && !((w0 >> (x0 & 31u)) & 1u)) unk_above &= ~32u;
             }
             if (SGC_STAMPS && (dbg & 512)) { const unsigned long long x = __builtin_amdgcn_s_memtime(); ts_dec += x - tsa; tsa = x; }
             bool fwd_it = false;
@@ -300,7 +310,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                     uint32_t b0 = 0;
                     if (lane == (uint32_t)__builtin_ctzll(bal)) b0 = atomicAdd(&n_fwd, (uint32_t)__popcll(bal));
                     b0 = __shfl(b0, __builtin_ctzll(bal), 64);
-                    if (fwd_it && !(dbg & 4096)) {
+                    if (fwd_it && !SGC_DBG(dbg, 4096u)) {
                         fwd[(uint64_t)wlo + b0 + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = rec;
                         const uint32_t q = run_part(out, rec);
                         if (q != RUN_DROP) atomicAdd(&hn[q], 1u);
@@ -314,10 +324,10 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
         printf("k_core<%d> wg %u wave %u: %u iters, load+unpack %llu scan %llu decide %llu out %llu total %llu ticks\n", (int)FINAL,
                blockIdx.x, t >> 6, n_it, ts_unp, ts_scan, ts_dec, ts_out, (unsigned long long)(__builtin_amdgcn_s_memtime() - ts_begin));
     __syncthreads();
-    if (cur_p != 0xFFFFFFFFu && !(dbg & 8192))
+    if (cur_p != 0xFFFFFFFFu && !SGC_DBG(dbg, 8192u))
         for (uint32_t i = t; i < SGC_CORE_EMAX; i += KC_THREADS) {
             const uint32_t v = cnt[i];
-            if (v) atomicAdd(&counts[tgid[i]], v);
+            if (v) atomicAdd(&counts[tgid[i] & 0x7FFFFFFFu], v);
         }
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
     if ((t & 63) == 0 && local) atomicAdd(&wsum, (unsigned long long)local);
@@ -328,7 +338,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
         __syncthreads();
         run_reserve(out, blockIdx.x, hn, rcur, wtmp, &rbase);
         const uint32_t nf = n_fwd;
-        for (uint32_t j0 = 0; j0 < nf && !(dbg & (4096u | 524288u)); j0 += 4 * KC_THREADS) {
+        for (uint32_t j0 = 0; j0 < nf && !SGC_DBG(dbg, 4096u | 524288u); j0 += 4 * KC_THREADS) {
             uint64_t r[4];
 #pragma unroll
             for (uint32_t k = 0; k < 4; k++) { const uint32_t j = j0 + k * KC_THREADS + t; if (j < nf) r[k] = fwd[(uint64_t)wlo + j]; }

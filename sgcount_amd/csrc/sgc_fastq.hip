@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(FQ_THREADS, 8) __attribute__((amdgpu_num_sgpr(
         rlo = tile == 0 ? 0u : seq_lines_before(ph, l0 + 1u < n_lines ? l0 + 1u : n_lines);
         rhi = seq_lines_before(ph, l1 + 1u < n_lines ? l1 + 1u : n_lines);
     }
-    if (a.dbg & 2u) return;
+    if (SGC_DBG(a.dbg, 2u)) return;
     for (uint32_t rb = rlo; rb < rhi || rb == rlo; rb += FQ_CAP) {
         // list the owned sequence lines [rb, rb + FQ_CAP): forward = stage offset of the line start, reverse = of its '\n'
         uint64_t mm = mine;
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(FQ_THREADS, 8) __attribute__((amdgpu_num_sgpr(
         __syncthreads();
         const uint32_t nrec = rhi - rb < FQ_CAP ? rhi - rb : FQ_CAP;
         // four lanes per listed line (a tile of ordinary reads holds ~200: one sweep of the 1024 lanes)
-        for (uint32_t i0 = 0; i0 < nrec && !(a.dbg & 1u); i0 += FQ_THREADS / 4u) {
+        for (uint32_t i0 = 0; i0 < nrec && !SGC_DBG(a.dbg, 1u); i0 += FQ_THREADS / 4u) {
             const uint32_t i = i0 + (t >> 2), sub = t & 3u;
             const bool have = i < nrec;
             uint32_t so = 0, len = 0; uint64_t go = 0; bool in_lds = true;

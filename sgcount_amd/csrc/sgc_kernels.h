@@ -1,5 +1,12 @@
 // sgc_kernels.h — host-callable launchers of the gfx950 kernels (sgc_kernels.hip).
 #pragma once
+// Timing-only ablation branches of the kernels (tools/tune.py: "what does this phase cost?" — results are WRONG when one is
+// taken) exist only in a library built with -DSGC_ABLATE=1 (SGC_HIPCC_FLAGS); in the shipped kernels SGC_DBG() is the
+// constant false, the branches and the scalar registers they held are gone, and sgc_set_option("dbg", != 0) is refused.
+#ifndef SGC_ABLATE
+#define SGC_ABLATE 0
+#endif
+#define SGC_DBG(word, bits) (SGC_ABLATE && ((word) & (bits)))
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -93,6 +100,9 @@ size_t sgc_device_build_scratch_bytes(uint32_t n, uint32_t L);
 int sgc_device_build_permute(hipStream_t st, const uint64_t *d_keys, uint32_t n, uint32_t L, const sgc_table_view &lib,
                              uint64_t *d_slots, uint32_t log2_slots, uint32_t gid_bits, uint64_t *d_bloom,
                              uint32_t bloom_log2, uint64_t *d_amb, unsigned long long *d_entries, void *d_scratch);
+
+// bit 31 of every guide id of a core index := "this guide has an ambiguous child" (after d_amb is complete on the stream)
+void sgc_flag_ambiguous(hipStream_t st, uint32_t *d_gids, uint64_t n_entries, const uint64_t *d_amb);
 
 // ---- FASTQ ingest (sgc_fastq.hip) -----------------------------------------------------------------
 // tile_scratch: sgc_fastq_tiles(n) + 1 u32.  sgc_launch_fastq_count leaves the newlines before every tile there and

@@ -106,6 +106,16 @@ __device__ __forceinline__ uint32_t part_of(uint64_t rec, uint64_t kmask, uint32
 // 8 KiB stride — a quarter less to write here and to read there, and both kernels run at what the memory system gives
 // this access pattern.  Blocks of the generic partition keep whole 8-byte records (their status does not fit).
 #define P6_HI_OFF (PART_BLOCK * 4u)
+// Records fall into the partitions evenly, so at any moment every open block of every workgroup of k_partition is filled to
+// about the same level: tens of thousands of concurrent write streams of ~0.5 KB runs that all target the SAME offset inside
+// their 4 KiB-aligned blocks — the same few memory channels (on physically contiguous memory, where nothing else scrambles
+// the address bits, the kernel runs a quarter slower: DESIGN.md §6).  So record j of slice block b sits in slot
+// (j + part_rot(b)) mod PART_BLOCK: the streams start at eight different 256-byte offsets, a whole wave still reads 64
+// consecutive slots.
+#ifndef PART_ROT
+#define PART_ROT 1
+#endif
+__device__ __forceinline__ uint32_t part_rot(uint32_t b) { return PART_ROT ? ((b * 2654435761u) >> 29) << 6 : 0u; }
 
 // ------------------------------------------------------------------------------------------------ K1
 template <int MODE>
@@ -229,7 +239,7 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
             const uint32_t at = j + (j - rn.x < rn.y ? rn.z : rn.w);       // record index in the pool (< 2^29: byte offsets fit 32 bits)
             char *pb = reinterpret_cast<char *>(pool);
             if (p6 && p != P) {
-                const uint32_t bo = (at >> PART_LOG2_BLOCK) << (PART_LOG2_BLOCK + 3u), idx = at & (PART_BLOCK - 1u);
+                const uint32_t bo = (at >> PART_LOG2_BLOCK) << (PART_LOG2_BLOCK + 3u), idx = (at + part_rot(at >> PART_LOG2_BLOCK)) & (PART_BLOCK - 1u);
                 *reinterpret_cast<uint32_t *>(pb + (size_t)(bo + (idx << 2))) = (uint32_t)r;
                 *reinterpret_cast<uint16_t *>(pb + (size_t)(bo + P6_HI_OFF + (idx << 1))) = (uint16_t)(r >> 32);
             } else {
@@ -261,6 +271,7 @@ template <bool P6>
 __device__ __forceinline__ uint64_t k2_record(const uint64_t *__restrict__ pool, uint32_t b, uint32_t j) {
     if (!P6) return pool[(uint64_t)b * PART_BLOCK + j];
     const char *bb = reinterpret_cast<const char *>(pool) + (uint64_t)b * (PART_BLOCK * 8u);
+    j = (j + part_rot(b)) & (PART_BLOCK - 1u);
     const uint32_t lo = reinterpret_cast<const uint32_t *>(bb)[j];
     const uint32_t hi = reinterpret_cast<const uint16_t *>(bb + P6_HI_OFF)[j];
     return (uint64_t)lo | ((uint64_t)hi << 32);
@@ -458,7 +469,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     // flush the slot counters: one atomic per occupied slot
     uint64_t local = 0;
     for (uint32_t i = t; i < slice; i += K2_THREADS) {
-        const uint32_t c = (dbg & 524288u) ? 0u : cnt[i];       // dbg 524288: timing-only, no flush
+        const uint32_t c = SGC_DBG(dbg, 524288u) ? 0u : cnt[i];       // dbg 524288: timing-only, no flush
         if (c) {
             atomicAdd(&counts[(uint32_t)(gslots[(uint64_t)p * slice + i] & ((1ull << gid_bits) - 1ull))], c);
             local += c;
@@ -471,7 +482,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     if ((t & 63) == 0 && local) atomicAdd(&wsum, (unsigned long long)local);
     __syncthreads();
     if (t == 0 && wsum) atomicAdd(matched, wsum);
-    if (!ep.recs || (dbg & 262144u)) return;
+    if (!ep.recs || SGC_DBG(dbg, 262144u)) return;
     // Epilogue (sgc_runs.h): what this workgroup could not settle — the misses it compacted to the fronts of its blocks —
     // and its share of the generic partition's blocks (records with an 'N' or a dead window: nothing to probe here) go to
     // core pass A, laid out by that pass's partitions in a region of ep.recs of the workgroup's own.  Two sweeps over the
@@ -504,7 +515,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 }
                 __syncthreads();
             }
-            if (dbg & (65536u << sweep)) continue;
+            if (SGC_DBG(dbg, 65536u << sweep)) continue;
             // DENSE: the misses are one contiguous run (walked once, with the first window), eight loads in flight per lane
             if (DENSE && !DIRECT && ws == s_lo && !(sweep == 0 && count_sub)) {
                 const uint32_t M = wmiss;
@@ -615,7 +626,7 @@ __global__ void __launch_bounds__(K3_THREADS) k_resolve_miss(const uint64_t *__r
         const uint32_t d = b0 + t < n_blocks ? desc[b0 + t] : 0;
         m_[t] = (d >> 16) == p_generic + 1 ? 0 : d & DESC_FILL_MASK;
     }
-    if (!(dbg & 16)) for (uint32_t i = t; i < (1u << SGC_LIB_BLOOM_LOG2_WORDS); i += K3_THREADS) lbf[i] = bl.words[i];
+    if (!SGC_DBG(dbg, 16u)) for (uint32_t i = t; i < (1u << SGC_LIB_BLOOM_LOG2_WORDS); i += K3_THREADS) lbf[i] = bl.words[i];
     __syncthreads();
     if (t == 0) {
         uint32_t run = 0;
@@ -641,7 +652,7 @@ __global__ void __launch_bounds__(K3_THREADS) k_resolve_miss(const uint64_t *__r
                 const uint32_t d = off_[u] + j;
                 if (d >= r0 && d < r0 + K3_STAGE) {
                     const uint64_t rec = __builtin_nontemporal_load(&blkp[(fr + j) & (PART_BLOCK - 1u)]);
-                    if ((rec >> sh) == 0 && !(dbg & 128)) st[atomicAdd(&n_fast, 1u)] = rec;
+                    if ((rec >> sh) == 0 && !SGC_DBG(dbg, 128u)) st[atomicAdd(&n_fast, 1u)] = rec;
                     else st[K3_STAGE - 1u - atomicAdd(&n_slow, 1u)] = rec;
                 }
             }
@@ -650,7 +661,7 @@ __global__ void __launch_bounds__(K3_THREADS) k_resolve_miss(const uint64_t *__r
         const uint32_t cntr = n_fast, cnts = n_slow;
         for (uint32_t k = t; k < cnts; k += K3_THREADS) {
             const uint64_t rec = st[K3_STAGE - 1u - k];
-            out[r0 + cntr + k] = (dbg & 128) ? SGC_NONE : sgc_assign<true>(rec & smask, rec >> sh, L, lib, perm, ONE_MM);
+            out[r0 + cntr + k] = SGC_DBG(dbg, 128u) ? SGC_NONE : sgc_assign<true>(rec & smask, rec >> sh, L, lib, perm, ONE_MM);
         }
         for (uint32_t d0 = 0; d0 < cntr; d0 += K3_THREADS * K3_R) {
             uint64_t rec[K3_R], fC[K3_R];
@@ -686,7 +697,7 @@ __global__ void __launch_bounds__(K3_THREADS) k_resolve_miss(const uint64_t *__r
                 pC[r] = false;
                 if (!ONE_MM || !live[r]) continue;
                 const uint64_t keyC = (rec[r] >> 2) & kmask;
-                pC[r] = (!PBLOOM || bloom_hit(fC[r], sgc_hash2(keyC))) && !(dbg & 64);
+                pC[r] = (!PBLOOM || bloom_hit(fC[r], sgc_hash2(keyC))) && !SGC_DBG(dbg, 64u);
                 if (pC[r]) { qC[r] = bucket_of(perm, keyC); a0[r] = load_bucket(perm, qC[r]); }
             }
 #pragma unroll
@@ -694,7 +705,7 @@ __global__ void __launch_bounds__(K3_THREADS) k_resolve_miss(const uint64_t *__r
                 if (!live[r]) continue;
                 if (pC[r]) x[r] = finish_find(perm, (rec[r] >> 2) & kmask, qC[r], a0[r]);
                 if (x[r] == SGC_NONE && mP[r]) x[r] = finish_find(lib, (rec[r] >> 4) & kmask, hP[r], a1[r]);
-                needB[r] = x[r] == SGC_NONE && !(dbg & 32);
+                needB[r] = x[r] == SGC_NONE && !SGC_DBG(dbg, 32u);
             }
             // round B
             uint64_t fP[K3_R], fM[K3_R];
@@ -868,7 +879,7 @@ void sgc_launch_part_k3(hipStream_t st, uint32_t L, const sgc_table_view &lib, c
                         const sgc_bloom_view &bloom_lib, const sgc_bloom_view &bloom_perm, const sgc_part_geometry &g,
                         const uint64_t *pool, const uint32_t *desc, uint32_t *seg_cnt, uint32_t *gids, uint32_t dbg) {
     const unsigned grid = (g.n_blocks + K3_SEG - 1) / K3_SEG;
-    if (one_mm && (dbg & 256))
+    if (one_mm && SGC_DBG(dbg, 256u))
         hipLaunchKernelGGL((k_resolve_miss<true, false>), dim3(grid), dim3(K3_THREADS), 0, st, pool, desc, g.n_blocks, g.partitions,
                            L, lib, perm, bloom_lib, bloom_perm, gids, seg_cnt, dbg);
     else if (one_mm)

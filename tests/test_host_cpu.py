@@ -312,3 +312,25 @@ def test_scanner_records_equal_the_host_packer(tmp_path):
     with pytest.raises(hostlib.HostError) as e:
         hostlib.scan_records(str(tmp_path / "trunc.fastq"), 20, threads=2, block_bytes=8192)
     assert e.value.code == 101 and "truncated" in str(e.value)
+
+
+def test_bgzf_followed_by_plain_gzip_members_is_read_as_gzip(tmp_path):
+    """bgzip output concatenated with ordinary gzip output is legal multi-member gzip (zlib and the reference's flate2 read
+    it): the member chain is checked when the file is opened and such a file takes the sequential inflater instead of
+    aborting with "corrupt BGZF member header" half way."""
+    import gzip
+    from sgcount_amd import hostlib
+    from sgcount_amd.bgzf import bgzf_bytes
+    a = b"".join(b"@a%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(4000))
+    b = b"".join(b"@b%d\nTTTTGGGGCC\n+\nIIIIIIIIII\n" % i for i in range(3000))
+    p = tmp_path / "mixed.fastq.gz"
+    p.write_bytes(bgzf_bytes(a, 20000, eof_marker=False) + gzip.compress(b))
+    body = a + b
+
+    def fnv(x):
+        h = 1469598103934665603
+        for c in x:
+            h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+    parts, nbytes, lines, h, first, flag = hostlib.text_feeder_walk(str(p), 1 << 16, 4)
+    assert (nbytes, lines, h) == (len(body), body.count(b"\n"), fnv(body)) and first == ord("@") and flag is True

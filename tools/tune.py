@@ -13,7 +13,7 @@ import statistics
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("SGC_ALLOW_DBG", "1")      # this tool may set the kernels' timing-only ablation flags
+# dbg=... ablation flags need a library built with SGC_HIPCC_FLAGS=-DSGC_ABLATE=1 (python -c "from sgcount_amd import build as b; b.build_one(b.SO, force=True)")
 
 
 def main():

@@ -29,7 +29,6 @@ def main():
     _ffi.check(dl.lib.sgc_sample_begin(dl.ctx, C.byref(smp), 0, 30, 1))
     dl.timing(True)
     if args.dbg:
-        os.environ["SGC_ALLOW_DBG"] = "1"
         dl.set_option("dbg", args.dbg << 24)
     for what in ("reads", "fastq"):
         tot_bytes, tot_ms, wall_ms = 0, 0.0, 0.0
