@@ -66,6 +66,7 @@ struct sgc_ctx {
     uint64_t place_info[4] = {0, 0, 0, 0};   // last search: candidates tried, peak transient bytes, duration in us, index of the one kept
     void *placed_pool = nullptr;       // the pool the trials chose (they run again if it was re-allocated since)
     bool six_byte = true;              // ... and the slice blocks hold six-byte records (needs direct, L <= 21)
+    bool five_byte = true;             // ... or five-byte records (needs direct and enough slices: 2 (L + 2) - slice bits <= 40)
     bool tag_sub = true;               // K1 tags the pass-A partition inside the slice, K2 counts misses by it (no histogram sweep)
     bool use_cuckoo = true;            // k_count_slices probes the two-choice image of the slices (no chain loop)
     uint32_t *d_lib_vals = nullptr, *d_perm_vals = nullptr;
@@ -311,7 +312,12 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
             // (runs region | miss runs | forward buffer); the run matrices get one more column per workgroup of a slice.
             // With them nothing but the probe loop reads the slice blocks, which then hold six-byte records if they fit.
             const bool direct = core_path && c->dense && c->direct && tag_sub && sgc_part_k2_grid(g) + sgc_part_k2_shares(g) <= 1024u;
-            const bool six = direct && c->six_byte && 2u * (c->L + 2u) + 2u <= 48u;
+            // what the slice blocks hold: 2 = five-byte records (the slice index is a prefix of the mixed core value, so a record keeps
+            // 2 (L + 2) - slice bits <= 40 bits), 1 = six-byte records (span + sub-partition <= 48 bits), 0 = whole 8-byte records
+            const uint32_t slice_bits = c->v_lib.log2_slots - c->v_lib.log2_slice;
+            const int six = !direct ? 0 :
+                            (c->five_byte && 2u * (c->L + 2u) - slice_bits <= 40u && slice_bits + (uint32_t)sub <= 2u * c->v_lib.core_cl) ? 2 :
+                            (c->six_byte && 2u * (c->L + 2u) + 2u <= 48u) ? 1 : 0;
             { timed t(c, T_PART); sgc_launch_part_k1(c->stream, p, chunk, c->L, c->v_lib, tag_sub ? (uint32_t)sub : 0u, g, pool, desc, six); }
             if (core_path) {
                 // everything the slice probe does not settle (its misses + the generic partition) is resolved in LDS by the
@@ -403,7 +409,7 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
                 if (done < n) { sgc_launch_fold(c->stream, s->d_c32, s->d_c64, c->n); s->since_fold = 0; }
                 continue;
             }
-            { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg, nullptr, c->use_cuckoo ? c->d_lib_cuckoo : nullptr, nullptr, nullptr, false, false); }
+            { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg, nullptr, c->use_cuckoo ? c->d_lib_cuckoo : nullptr, nullptr, nullptr, false, 0); }
             rc = ensure(&c->d_gids, &c->gids_cap, g.gids_bytes);                // one slot per pool record: every read may miss
             if (rc) return rc;
             rc = ensure(&c->d_aux, &c->aux_cap, ((size_t)g.n_segs + 1) * 4);
@@ -612,6 +618,7 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
     if (!strcmp(key, "dense")) { c->dense = value != 0; return SGC_OK; }
     if (!strcmp(key, "direct")) { c->direct = value != 0; return SGC_OK; }
     if (!strcmp(key, "six_byte")) { c->six_byte = value != 0; return SGC_OK; }
+    if (!strcmp(key, "five_byte")) { c->five_byte = value != 0; return SGC_OK; }
     if (!strcmp(key, "tag_sub")) { c->tag_sub = value != 0; return SGC_OK; }
     if (!strcmp(key, "cuckoo")) { c->use_cuckoo = value != 0; return SGC_OK; }
     if (!strcmp(key, "rest_filter")) { c->rest_filter = value != 0; return SGC_OK; }         // takes effect at the next sgc_set_library

@@ -204,7 +204,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             uint32_t k0 = 0, k1 = 0, k2 = 0;                              // entry of the (last) one
             uint32_t d0 = 0, d1 = 0, d2 = 0;                              // its differing base (one bit of the rest)
             if (vis && !SGC_DBG(dbg, 1024u)) {
-                const uint32_t b = sgc_core_home(sgc_core_hash(corev), cv.log2_p);
+                const uint32_t b = sgc_core_home(sgc_core_hash(corev, cl), cv.log2_p);
                 const uint32_t e_end = start[b + 1];
                 for (uint32_t i = start[b]; i < e_end; i++) {
                     const uint64_t e = ent[i];
@@ -375,7 +375,7 @@ static sgc_runs make_runs(uint64_t *recs, void *mats, size_t mat_bytes, uint32_t
     r.recs = recs; r.cnt = (uint32_t *)mats; r.off = (uint32_t *)((char *)mats + mat_bytes); r.tot = tot; r.cursor = cursor; r.W = W;
     r.sub_bits = 0xFFu;
     r.cs2 = 2 * cv.cs; r.log2_p = cv.log2_p; r.sh = 2 * K; r.dead_all = SGC_STATE_DEAD * (1 + K + K * K);
-    r.cmask = (1ull << (2 * cv.cl)) - 1ull;
+    r.cmask = (1ull << (2 * cv.cl)) - 1ull; r.cl = cv.cl;
     return r;
 }
 

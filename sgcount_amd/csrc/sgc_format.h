@@ -122,26 +122,38 @@ struct sgc_core_view {
     const uint32_t *filt;
 };
 SGC_HD uint32_t sgc_rest_hash(uint32_t rest, uint32_t log2_bits) { return (rest * 0x9E3779B1u) >> (32 - log2_bits); }
-// 32-bit hash of a core value (<= 28 bits): its top bits pick the partition, the next ones the bucket.  One multiply
-// (Fibonacci hashing): the partition kernel evaluates it for every read, and 32-bit multiplies run at quarter rate.
-SGC_HD uint32_t sgc_core_hash(uint32_t corev) { return corev * 0x9E3779B1u; }
+// Hash of a core value (cl bases = 2 cl bits, cl <= 14): its top 2 cl bits are a BIJECTION of the core value (an odd multiplier
+// modulo 2^(2 cl): sgc_core_mix / sgc_core_unmix), the bits below are zero.  The library slice, the partition of a core pass and
+// the bucket inside the partition are successive prefixes of it, so (a) a bucket of a core index holds the entries of as few
+// distinct core values as the bits allow — for L = 20 exactly one: a bucket scan meets only true candidates — and (b) a record
+// that sits in a slice's block need not store the slice bits: the five-byte slice records of k_partition keep the remaining
+// 2 cl - (slice bits) bits of the mixed value in place of the core bases and k_count_slices rebuilds the core value with one
+// multiply.  One multiply to evaluate (the partition kernel does it for every read, and 32-bit multiplies run at quarter rate).
+#define SGC_CORE_M1 0x9E3779B1u
+#define SGC_CORE_M1_INV 0x0E8B2F51u      // SGC_CORE_M1 * SGC_CORE_M1_INV == 1 (mod 2^32), hence modulo every 2^k
+SGC_HD uint32_t sgc_core_mix(uint32_t corev, uint32_t cl) { return (corev * SGC_CORE_M1) & (uint32_t)((1ull << (2 * cl)) - 1ull); }
+SGC_HD uint32_t sgc_core_unmix(uint32_t h, uint32_t cl) { return (h * SGC_CORE_M1_INV) & (uint32_t)((1ull << (2 * cl)) - 1ull); }
+SGC_HD uint32_t sgc_core_hash(uint32_t corev, uint32_t cl) { return (corev * SGC_CORE_M1) << (32 - 2 * cl); }
 // 32-bit hash of a whole key, for the bucket inside a core-hashed slice (one multiply instead of the 64-bit sgc_hash)
 SGC_HD uint32_t sgc_hash32(uint64_t key) { return (uint32_t)(key ^ (key >> 29)) * 0x85EBCA6Bu; }
 SGC_HD uint32_t sgc_core_part(uint32_t h, uint32_t log2_p) { return log2_p ? h >> (32 - log2_p) : 0u; }
+// the same from the mixed value alone (needs log2_p <= 2 cl)
+SGC_HD uint32_t sgc_core_part_mix(uint32_t mix, uint32_t cl, uint32_t log2_p) { return mix >> (2 * cl - log2_p); }
 // Home bucket of a key in a sliced table whose slices follow the core hash (sgc_table_view::core_cl): slice = the top
 // bits of the hash of key bases [1, 1 + core_cl) (= span bases [2, 2 + core_cl): core A as the Centered window sees
-// it), bucket inside the slice = the top bits of the full-key hash.
+// it), bucket inside the slice = the top bits of the full-key hash.  (The builder only makes such slices when their index
+// fits the mixed value: log2_slots - log2_slice <= 2 core_cl.)
 SGC_HD uint32_t sgc_home_bucket_ex(uint64_t key, uint32_t log2_slots, uint32_t log2_slice, uint32_t core_cl) {
     if (core_cl == 0 || log2_slice >= log2_slots) return sgc_home_bucket(key, log2_slots);
-    const uint32_t hc = sgc_core_hash((uint32_t)((key >> 2) & ((1ull << (2 * core_cl)) - 1ull)));
-    return (sgc_core_part(hc, log2_slots - log2_slice) << (log2_slice - 1)) | (sgc_hash32(key) >> (33 - log2_slice));
+    const uint32_t hm = sgc_core_mix((uint32_t)((key >> 2) & ((1ull << (2 * core_cl)) - 1ull)), core_cl);
+    return (sgc_core_part_mix(hm, core_cl, log2_slots - log2_slice) << (log2_slice - 1)) | (sgc_hash32(key) >> (33 - log2_slice));
 }
 // Home SLOT of a key (log2_slots bits); its upper bits are sgc_home_bucket_ex.  The slot inside the slice is what
 // k_partition tags into a clean record and where the two-choice image below looks first.
 SGC_HD uint32_t sgc_home_slot_ex(uint64_t key, uint32_t log2_slots, uint32_t log2_slice, uint32_t core_cl) {
     if (core_cl == 0 || log2_slice >= log2_slots) return (uint32_t)(sgc_hash(key) >> (64 - log2_slots));
-    const uint32_t hc = sgc_core_hash((uint32_t)((key >> 2) & ((1ull << (2 * core_cl)) - 1ull)));
-    return (sgc_core_part(hc, log2_slots - log2_slice) << log2_slice) | (sgc_hash32(key) >> (32 - log2_slice));
+    const uint32_t hm = sgc_core_mix((uint32_t)((key >> 2) & ((1ull << (2 * core_cl)) - 1ull)), core_cl);
+    return (sgc_core_part_mix(hm, core_cl, log2_slots - log2_slice) << log2_slice) | (sgc_hash32(key) >> (32 - log2_slice));
 }
 // Two-choice image of a library slice for k_count_slices (sgc_part.hip): ONE-slot buckets, a key sits in its home slot s1
 // (inside the slice) or in the alternate slot s1 ^ d(key), d != 0 — both are read at once (two 8-byte LDS reads: a random

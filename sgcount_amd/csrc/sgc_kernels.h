@@ -55,7 +55,7 @@ void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_
 // sub_bits: with core-hashed slices, log2 (1..2) of core pass A's partitions per slice, tagged into the clean records; else 0
 void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib, uint32_t sub_bits,
                         const sgc_part_geometry &g, uint64_t *pool, uint32_t *desc,
-                        bool six_byte /* slice blocks as 6-byte records: only with direct runs, core-hashed slices, 2 (L + 2) + 2 <= 48 */);
+                        int slice_rec /* what the slice blocks hold: 0 = 8-byte records, 1 = six-byte (direct runs, core-hashed slices, 2 (L + 2) + 2 <= 48), 2 = five-byte (2 (L + 2) - slice bits <= 40) */);
 struct sgc_runs;       // sgc_runs.h
 // runs != NULL: the leftovers (misses, generic blocks) are laid out as the runs of core pass A by the kernel's epilogue
 uint32_t sgc_part_k2_grid(const sgc_part_geometry &g);
@@ -68,7 +68,7 @@ void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, c
                         bool direct_runs /* with mrun and tagged sub-partitions: the misses go straight to per-partition runs that are
                                             pass A's input (mrun: pool records << runs->sub_bits, inside runs->recs' allocation; the run
                                             matrices have shares + grid columns) */,
-                        bool six_byte /* as given to sgc_launch_part_k1 */);
+                        int slice_rec /* as given to sgc_launch_part_k1 */);
 void sgc_launch_part_k3(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm,
                         const sgc_bloom_view &bloom_lib, const sgc_bloom_view &bloom_perm, const sgc_part_geometry &g,
                         const uint64_t *pool, const uint32_t *desc, uint32_t *seg_cnt, uint32_t *gids, uint32_t dbg);

@@ -77,9 +77,12 @@ __device__ __forceinline__ uint32_t part_front(uint32_t b) { return ((b * 265443
 //   1  core-hashed slices, 8-byte records, slot tag + sub-partition tag
 //   2  core-hashed slices, six-byte records (below): the home slot is not tagged (k_count_slices hashes the key again:
 //      one multiply) and the sub-partition sits right above the span, so that a clean record is 2 (L + 2) + 2 <= 48 bits
-// Returns the partition; `tag` is what to OR into the record (0 for the generic partition).
+//   3  core-hashed slices, FIVE-byte records (below): the slice index is a prefix of the mixed core value (sgc_core_mix, a
+//      bijection), so a record inside a slice's block keeps only the rest of it in place of its core bases — 2 (L + 2) minus
+//      the slice bits <= 40 bits; the sub-partition is the top of what is kept
+// Returns the partition; `tag` is what to OR into the record (0 for the generic partition); MODE 3 replaces the record.
 template <int MODE>
-__device__ __forceinline__ uint32_t part_of(uint64_t rec, uint64_t kmask, uint32_t sh, uint32_t log2_slots, uint32_t log2_slice,
+__device__ __forceinline__ uint32_t part_of(uint64_t &rec, uint64_t kmask, uint32_t sh, uint32_t log2_slots, uint32_t log2_slice,
                                             uint32_t core_cl, uint32_t sub_bits, uint64_t &tag) {
     const bool generic = (rec >> sh) != 0;
     const uint64_t key = (rec >> 2) & kmask;
@@ -89,12 +92,16 @@ __device__ __forceinline__ uint32_t part_of(uint64_t rec, uint64_t kmask, uint32
         tag = (uint64_t)(hs & ((1u << log2_slice) - 1u)) << PART_TAG_SHIFT;
         p = hs >> log2_slice;
     } else {
-        // the slice and the sub-partition are prefixes of ONE hash of the core-A bases (log2_slots > log2_slice here)
-        const uint32_t n = log2_slots - log2_slice;
-        const uint32_t hc = sgc_core_hash((uint32_t)((key >> 2) & ((1ull << (2 * core_cl)) - 1ull)));
-        const uint32_t part = hc >> (32u - n - sub_bits), sub = part & ((1u << sub_bits) - 1u);
+        // the slice and the sub-partition are prefixes of ONE mixed value of the core-A bases (log2_slots > log2_slice here)
+        const uint32_t n = log2_slots - log2_slice, cb = 2u * core_cl;
+        const uint32_t hm = sgc_core_mix((uint32_t)((key >> 2) & ((1ull << cb) - 1ull)), core_cl);
+        const uint32_t part = hm >> (cb - n - sub_bits), sub = part & ((1u << sub_bits) - 1u);
         p = part >> sub_bits;
-        if (MODE == 2) tag = (uint64_t)sub << sh;
+        if (MODE == 3) {
+            tag = 0;
+            // span bits [0, 4) | the mixed value below the slice index | span bits above the core, closed up
+            if (!generic) rec = (rec & 0xFull) | ((uint64_t)(hm & ((1u << (cb - n)) - 1u)) << 4) | ((rec >> (4u + cb)) << (4u + cb - n));
+        } else if (MODE == 2) tag = (uint64_t)sub << sh;
         else tag = ((uint64_t)(sgc_hash32(key) >> (32u - log2_slice)) << PART_TAG_SHIFT) | ((uint64_t)sub << PART_SUB_SHIFT);
     }
     if (generic) { tag = 0; p = 1u << (log2_slots - log2_slice); }
@@ -106,6 +113,7 @@ __device__ __forceinline__ uint32_t part_of(uint64_t rec, uint64_t kmask, uint32
 // 8 KiB stride — a quarter less to write here and to read there, and both kernels run at what the memory system gives
 // this access pattern.  Blocks of the generic partition keep whole 8-byte records (their status does not fit).
 #define P6_HI_OFF (PART_BLOCK * 4u)
+// Five-byte slice blocks (MODE 3): PART_BLOCK x u32 followed by PART_BLOCK x u8 (bits 32..39), 2.5 KiB of the block's stride.
 // Records fall into the partitions evenly, so at any moment every open block of every workgroup of k_partition is filled to
 // about the same level: tens of thousands of concurrent write streams of ~0.5 KB runs that all target the SAME offset inside
 // their 4 KiB-aligned blocks — the same few memory channels (on physically contiguous memory, where nothing else scrambles
@@ -113,7 +121,7 @@ __device__ __forceinline__ uint32_t part_of(uint64_t rec, uint64_t kmask, uint32
 // (j + part_rot(b)) mod PART_BLOCK: the streams start at eight different 256-byte offsets, a whole wave still reads 64
 // consecutive slots.
 #ifndef PART_ROT
-#define PART_ROT 1
+#define PART_ROT 0
 #endif
 __device__ __forceinline__ uint32_t part_rot(uint32_t b) { return PART_ROT ? ((b * 2654435761u) >> 29) << 6 : 0u; }
 
@@ -125,7 +133,7 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
                                                    uint32_t *__restrict__ desc, uint32_t *__restrict__ tail,
                                                    uint32_t tail_words, uint32_t *__restrict__ wcnt,
                                                    uint32_t *__restrict__ wlist) {
-    constexpr bool p6 = MODE == 2;
+    constexpr bool p6 = MODE == 2, p5 = MODE == 3;
     __shared__ uint64_t stage[PART_TILE];
     __shared__ uint8_t stage_p[PART_TILE];               // partition of every staged record
     __shared__ uint32_t cnt[PART_ARR], start[PART_ARR], blk[PART_ARR], fill[PART_ARR];
@@ -238,10 +246,11 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
             const uint4 rn = runs[p];
             const uint32_t at = j + (j - rn.x < rn.y ? rn.z : rn.w);       // record index in the pool (< 2^29: byte offsets fit 32 bits)
             char *pb = reinterpret_cast<char *>(pool);
-            if (p6 && p != P) {
+            if ((p6 || p5) && p != P) {
                 const uint32_t bo = (at >> PART_LOG2_BLOCK) << (PART_LOG2_BLOCK + 3u), idx = (at + part_rot(at >> PART_LOG2_BLOCK)) & (PART_BLOCK - 1u);
                 *reinterpret_cast<uint32_t *>(pb + (size_t)(bo + (idx << 2))) = (uint32_t)r;
-                *reinterpret_cast<uint16_t *>(pb + (size_t)(bo + P6_HI_OFF + (idx << 1))) = (uint16_t)(r >> 32);
+                if (p5) *reinterpret_cast<uint8_t *>(pb + (size_t)(bo + P6_HI_OFF + idx)) = (uint8_t)(r >> 32);
+                else *reinterpret_cast<uint16_t *>(pb + (size_t)(bo + P6_HI_OFF + (idx << 1))) = (uint16_t)(r >> 32);
             } else {
                 *reinterpret_cast<uint64_t *>(pb + (size_t)(at << 3)) = r;
             }
@@ -267,13 +276,14 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
 #define K2_SCAN 16u              // descriptors examined per lane per scan chunk
 #define K2_GLIST 64u             // generic blocks listed per epilogue window
 // record j of slice block b
-template <bool P6>
+// REC: 0 = 8-byte records, 1 = six-byte, 2 = five-byte blocks
+template <int REC>
 __device__ __forceinline__ uint64_t k2_record(const uint64_t *__restrict__ pool, uint32_t b, uint32_t j) {
-    if (!P6) return pool[(uint64_t)b * PART_BLOCK + j];
+    if (REC == 0) return pool[(uint64_t)b * PART_BLOCK + j];
     const char *bb = reinterpret_cast<const char *>(pool) + (uint64_t)b * (PART_BLOCK * 8u);
     j = (j + part_rot(b)) & (PART_BLOCK - 1u);
     const uint32_t lo = reinterpret_cast<const uint32_t *>(bb)[j];
-    const uint32_t hi = reinterpret_cast<const uint16_t *>(bb + P6_HI_OFF)[j];
+    const uint32_t hi = REC == 2 ? (uint32_t)reinterpret_cast<const uint8_t *>(bb + P6_HI_OFF)[j] : (uint32_t)reinterpret_cast<const uint16_t *>(bb + P6_HI_OFF)[j];
     return (uint64_t)lo | ((uint64_t)hi << 32);
 }
 
@@ -290,8 +300,10 @@ __device__ __forceinline__ uint64_t k2_record(const uint64_t *__restrict__ pool,
 // its slice) of the run matrices, nothing is read back or moved.  Only the workgroup's share of the generic blocks still goes
 // through the epilogue's histogram + placement, as producer column G + blockIdx.x.  mrun must be ep.recs + (an offset that
 // fits 32 bits); ep.W = G + gridDim.x.
-// P6 (with DIRECT): the slice blocks hold six-byte records (k_partition, P6_HI_OFF).
-template <int LOG2_SLICE, bool CUCKOO, bool DENSE, bool DIRECT, bool P6>
+// REC (with DIRECT): 1 = the slice blocks hold six-byte records (k_partition, P6_HI_OFF), 2 = five-byte records: a record is
+// its span with the core-A bases replaced by the mixed core value below the slice index; the span comes back with one multiply
+// (sgc_core_unmix) — this kernel waits for its pool bytes, not for its arithmetic.
+template <int LOG2_SLICE, bool CUCKOO, bool DENSE, bool DIRECT, int REC>
 __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(80))) k_count_slices(uint64_t *__restrict__ pool, uint32_t *__restrict__ desc,
                                                              const uint32_t *__restrict__ wcnt, const uint32_t *__restrict__ wlist,
                                                              uint32_t k1_wgs, uint32_t blocks_per_wg, uint32_t G, uint32_t L,
@@ -300,6 +312,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                                                              const sgc_runs ep, const uint64_t *__restrict__ cuck,
                                                              uint64_t *__restrict__ mrun, uint32_t *__restrict__ mcur) {
     constexpr uint32_t S = 1u << LOG2_SLICE;
+    constexpr bool P6 = REC != 0;                            // packed slice blocks: no slot tag in the record, the key is hashed here
     // A step of the workgroup takes BPS blocks side by side: lanes [h PART_BLOCK, (h + 1) PART_BLOCK) take record jl of the
     // h-th of them (h is wave-uniform: a block is a whole number of waves); a group is K2_U steps.
     static_assert(PART_BLOCK <= K2_THREADS && PART_BLOCK >= 64u, "a block is 1..16 waves of the workgroup");
@@ -371,7 +384,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
         for (uint32_t u = 0; u < K2_U; u++) {
             ce[u] = K2_ENTRY(u);
             // lanes past the block's fill have nothing to read (one open block per K1 workgroup and slice is part empty)
-            cur[u] = (ce[u] != 0xFFFFFFFFu && jl <= (ce[u] & 2047u)) ? k2_record<P6>(pool, ce[u] >> 11, jl) : 0ull;
+            cur[u] = (ce[u] != 0xFFFFFFFFu && jl <= (ce[u] & 2047u)) ? k2_record<REC>(pool, ce[u] >> 11, jl) : 0ull;
         }
         for (uint32_t li = 0; li < nsteps; li += K2_U) {
             const uint32_t par = (li / K2_U) & 1u;
@@ -387,7 +400,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
 #pragma unroll
             for (uint32_t u = 0; u < K2_U; u++) {
                 const uint32_t ne = K2_ENTRY(li + K2_U + u);
-                nxt[u] = (ne != 0xFFFFFFFFu && jl <= (ne & 2047u)) ? k2_record<P6>(pool, ne >> 11, jl) : 0ull;
+                nxt[u] = (ne != 0xFFFFFFFFu && jl <= (ne & 2047u)) ? k2_record<REC>(pool, ne >> 11, jl) : 0ull;
             }
             // Centered-exact probe (src/counter.rs:111) of the Q records against the slice in LDS.  The LDS copy
             // holds bare keys, so a bucket resolves with four 64-bit compares and no branches (K2 is bound by
@@ -399,6 +412,16 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 // only holds clean records: no status test here
                 const uint32_t u = q;
                 const bool valid = ce[u] != 0xFFFFFFFFu && jl <= (ce[u] & 2047u);
+                if (REC == 2) {
+                    // five-byte record -> span: bits [0, 4) | core value << 4 | the rest above; the core value is the inverse of
+                    // (slice index : kept bits) under the mixing multiply
+                    const uint32_t cb = 2u * lib.core_cl, kb = cb - (lib.log2_slots - lib.log2_slice);
+                    const uint32_t raw_lo = (uint32_t)cur[q];
+                    const uint32_t hmix = (p << kb) | ((raw_lo >> 4) & ((1u << kb) - 1u));
+                    const uint32_t corev = sgc_core_unmix(hmix, lib.core_cl);
+                    cur[q] = (uint64_t)(raw_lo & 0xFu) | ((uint64_t)corev << 4) | ((cur[q] >> (4u + kb)) << (4u + cb)) |
+                             ((uint64_t)((hmix >> (kb - ep.sub_bits)) & ((1u << ep.sub_bits) - 1u)) << (2u * (L + 2u)));      // + the sub-partition where the six-byte record has it
+                }
                 const uint64_t key = (cur[q] >> 2) & kmask;
                 // home slot inside the slice: left there by k_partition, or (six-byte records) hashed again here
                 const uint32_t s1 = P6 ? sgc_hash32(key) >> (32u - ls) : (uint32_t)(cur[q] >> PART_TAG_SHIFT);
@@ -841,13 +864,14 @@ void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_
 }
 
 void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib, uint32_t sub_bits,
-                        const sgc_part_geometry &g, uint64_t *pool, uint32_t *desc, bool six_byte) {
+                        const sgc_part_geometry &g, uint64_t *pool, uint32_t *desc, int slice_rec) {
     const bool core_hashed = lib.core_cl != 0 && lib.log2_slice < lib.log2_slots;
 #define K1_LAUNCH(MODE)                                                                                                            \
     hipLaunchKernelGGL((k_partition<MODE>), dim3(g.k1_wgs), dim3(K1_THREADS), 0, st, recs, n, g.per_wg, g.blocks_per_wg, L,          \
                        lib.log2_slots, lib.log2_slice, lib.core_cl, sub_bits, pool, desc, (uint32_t *)((char *)desc + g.desc_tail_off), \
                        SGC_DESC_TAIL / 4, (uint32_t *)((char *)desc + g.wcnt_off), (uint32_t *)((char *)desc + g.wlist_off))
-    if (six_byte && core_hashed) K1_LAUNCH(2);
+    if (slice_rec == 2 && core_hashed) K1_LAUNCH(3);
+    else if (slice_rec == 1 && core_hashed) K1_LAUNCH(2);
     else if (core_hashed) K1_LAUNCH(1);
     else K1_LAUNCH(0);
 #undef K1_LAUNCH
@@ -860,18 +884,18 @@ uint32_t sgc_part_k2_shares(const sgc_part_geometry &g) { return k2_shares(g); }
 
 void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_part_geometry &g,
                         uint64_t *pool, uint32_t *desc, uint32_t *counts, unsigned long long *matched, uint32_t dbg,
-                        const sgc_runs *runs, const uint64_t *cuckoo, uint64_t *mrun, uint32_t *mcur, bool direct_runs, bool six_byte) {
+                        const sgc_runs *runs, const uint64_t *cuckoo, uint64_t *mrun, uint32_t *mcur, bool direct_runs, int slice_rec) {
     const uint32_t G = k2_shares(g);
     sgc_runs none{};
     const uint32_t *wcnt = (const uint32_t *)((const char *)desc + g.wcnt_off), *wlist = (const uint32_t *)((const char *)desc + g.wlist_off);
     const bool dense = runs && mrun;
     const bool direct = dense && direct_runs && runs->sub_bits != 0xFFu;
-#define K2_LAUNCH(CK, DN, DR, P6)                                                                                                      \
-    hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE, CK, DN, DR, P6>), dim3(g.partitions * G), dim3(K2_THREADS), 0, st, pool, desc, wcnt, wlist, \
+#define K2_LAUNCH(CK, DN, DR, REC)                                                                                                     \
+    hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE, CK, DN, DR, REC>), dim3(g.partitions * G), dim3(K2_THREADS), 0, st, pool, desc, wcnt, wlist, \
                        g.k1_wgs, g.blocks_per_wg, G, L, lib, counts, matched, dbg, runs ? *runs : none, cuckoo, mrun, mcur)
-    const bool p6 = direct && six_byte;
-    if (cuckoo) { if (p6) K2_LAUNCH(true, true, true, true); else if (direct) K2_LAUNCH(true, true, true, false); else if (dense) K2_LAUNCH(true, true, false, false); else K2_LAUNCH(true, false, false, false); }
-    else { if (p6) K2_LAUNCH(false, true, true, true); else if (direct) K2_LAUNCH(false, true, true, false); else if (dense) K2_LAUNCH(false, true, false, false); else K2_LAUNCH(false, false, false, false); }
+    const int rec = direct ? slice_rec : 0;          // 0 = 8-byte, 1 = six-byte, 2 = five-byte slice blocks
+    if (cuckoo) { if (rec == 2) K2_LAUNCH(true, true, true, 2); else if (rec == 1) K2_LAUNCH(true, true, true, 1); else if (direct) K2_LAUNCH(true, true, true, 0); else if (dense) K2_LAUNCH(true, true, false, 0); else K2_LAUNCH(true, false, false, 0); }
+    else { if (rec == 2) K2_LAUNCH(false, true, true, 2); else if (rec == 1) K2_LAUNCH(false, true, true, 1); else if (direct) K2_LAUNCH(false, true, true, 0); else if (dense) K2_LAUNCH(false, true, false, 0); else K2_LAUNCH(false, false, false, 0); }
 #undef K2_LAUNCH
 }
 

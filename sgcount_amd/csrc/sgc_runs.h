@@ -30,13 +30,13 @@ struct sgc_runs {
     // partition function of the consuming pass: hash of the record's core bases, or RUN_DROP for a record whose
     // three windows are all dead (a read too short for the Centered window, src/counter.rs:158-166: it cannot match,
     // and all such records are identical, so they would pile up in one partition)
-    uint32_t cs2, log2_p, sh, dead_all;
+    uint32_t cs2, log2_p, sh, dead_all, cl;
     uint64_t cmask;
 };
 
 __device__ __forceinline__ uint32_t run_part(const sgc_runs &r, uint64_t rec) {
     if ((uint32_t)(rec >> r.sh) == r.dead_all) return RUN_DROP;
-    return sgc_core_part(sgc_core_hash((uint32_t)((rec >> r.cs2) & r.cmask)), r.log2_p);
+    return sgc_core_part(sgc_core_hash((uint32_t)((rec >> r.cs2) & r.cmask), r.cl), r.log2_p);
 }
 
 // Producer epilogue, part 1 (all threads of a 1024-lane workgroup; hn[p] = this workgroup's records per partition,

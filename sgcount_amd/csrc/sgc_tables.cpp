@@ -103,7 +103,9 @@ int sgc_build_library_table(const uint8_t *seqs, uint32_t n, uint32_t L, uint32_
     out.core_cl = 0;
     if (core_cl) {
         table_alloc(out, n, 0.4, choose_gid_bits(n, L), max_log2_slice, 0);
-        if (out.log2_slice < out.log2_slots && !slice_overfull(keys, out.log2_slots, out.log2_slice, core_cl, 0.6)) out.core_cl = core_cl;
+        // (the slice index must be a prefix of the mixed core value: no more slice bits than core bits)
+        if (out.log2_slice < out.log2_slots && out.log2_slots - out.log2_slice <= 2 * core_cl &&
+            !slice_overfull(keys, out.log2_slots, out.log2_slice, core_cl, 0.6)) out.core_cl = core_cl;
     }
     if (!out.core_cl) {
         uint32_t extra = 0;
@@ -211,7 +213,7 @@ bool sgc_build_core_index(const std::vector<uint64_t> &keys, uint32_t L, uint32_
     std::vector<uint32_t> h((size_t)n * 3);
     for (uint32_t g = 0; g < n; g++)
         for (uint32_t a = 0; a < 3; a++)               // window position of span base cs at alignment a: cs - a
-            h[(size_t)g * 3 + a] = sgc_core_hash((uint32_t)((keys[g] >> (2 * (cs - a))) & cmask));
+            h[(size_t)g * 3 + a] = sgc_core_hash((uint32_t)((keys[g] >> (2 * (cs - a))) & cmask), cl);
     uint32_t lp = 0;
     std::vector<uint32_t> fill;
     for (;; lp++) {

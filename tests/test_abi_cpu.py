@@ -88,6 +88,31 @@ def test_k2_group_hash_is_balanced():
         assert counts.max() < 1.1 * counts.mean() + 8 and counts.min() > 0.9 * counts.mean() - 8, (G, counts.min(), counts.max())
 
 
+def test_core_mix_is_a_balanced_bijection():
+    """sgc_format.h sgc_core_mix: (core value * 0x9E3779B1) mod 2^(2 cl) must be a bijection — the five-byte slice records of
+    k_partition drop the slice index and k_count_slices rebuilds the core value with the inverse multiplier 0x0E8B2F51 — and
+    its top bits, which pick the library slice and the partition of core pass A, must spread both all core values and random
+    subsets of them (a library's guides) evenly."""
+    M, MINV = 0x9E3779B1, 0x0E8B2F51
+    assert (M * MINV) % (1 << 32) == 1
+    rng = np.random.default_rng(3)
+    for cl in (1, 4, 9, 11, 14):
+        bits = 2 * cl
+        mask = (1 << bits) - 1
+        n = min(1 << bits, 1 << 20)
+        x = np.arange(1 << bits, dtype=np.uint64) if n == 1 << bits else rng.integers(0, 1 << bits, n, dtype=np.uint64)
+        h = (x * np.uint64(M)) & np.uint64(mask)
+        assert np.array_equal((h * np.uint64(MINV)) & np.uint64(mask), x)
+        if n == 1 << bits:
+            assert len(np.unique(h)) == n
+        if bits >= 16:
+            sample = rng.choice(x, 100_000, replace=False) if n > 100_000 else x
+            hs = (sample * np.uint64(M)) & np.uint64(mask)
+            for lp in (6, 8):
+                counts = np.bincount((hs >> np.uint64(bits - lp)).astype(np.int64), minlength=1 << lp)
+                assert counts.max() < 1.25 * counts.mean() + 8 and counts.min() > 0.75 * counts.mean() - 8, (cl, lp, counts.min(), counts.max())
+
+
 def test_status_division_magic():
     """k_core decodes status = sC + K (sP + K sM) with n // K == (n * (2^20 // K + 1)) >> 20; exact for every
     status a record can carry (n < K^3, K = L + 2 <= 25 for one-u64 records)."""

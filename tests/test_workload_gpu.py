@@ -84,7 +84,7 @@ def test_synthetic_workload_vs_oracle_2m(env, exact):
 
 @pytest.mark.parametrize("exact", [False, True])
 def test_every_fallback_mode_gives_the_same_table(env, exact):
-    """The shipped pass is a stack of results-preserving choices (six-byte slice blocks > direct miss runs > dense runs >
+    """The shipped pass is a stack of results-preserving choices (five-byte > six-byte slice blocks > direct miss runs > dense runs >
     sub-partition tag > two-choice image > core-hashed slices); each one has a fallback that libraries of other shapes take
     (L >= 22, slices that do not follow the core hash, ...).  Every rung of that ladder must count the same table — the
     oracle's — on the same 1M reads."""
@@ -92,7 +92,7 @@ def test_every_fallback_mode_gives_the_same_table(env, exact):
     n, ng = 1_000_000, 20_000
     lib_text = None
     want = None
-    ladder = [({}, {}), ({}, {"six_byte": 0}), ({}, {"direct": 0}), ({}, {"dense": 0}), ({}, {"tag_sub": 0}), ({}, {"cuckoo": 0}),
+    ladder = [({}, {}), ({}, {"five_byte": 0}), ({}, {"five_byte": 0, "six_byte": 0}), ({}, {"direct": 0}), ({}, {"dense": 0}), ({}, {"tag_sub": 0}), ({}, {"cuckoo": 0}),
               ({}, {"direct": 0, "cuckoo": 0, "tag_sub": 0}), ({"align_slices": 0}, {}), ({"align_slices": 0}, {"dense": 0, "cuckoo": 0}),
               ({"rest_filter": 0}, {}), ({}, {"variant": 3}), ({}, {"variant": 1})]
     for lib_opts, opts in ladder:

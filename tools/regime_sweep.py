@@ -10,10 +10,15 @@ from sgcount_amd.workload import DeviceWorkload         # noqa: E402
 
 wl = DeviceWorkload(100_000_000, 100_000, 20, one_mismatch=True)
 for spec in sys.argv[1:]:
+    keep = False
     for kv in filter(None, spec.split(",")):
+        if kv == "keep":                      # same scratch allocations as the spec before: the regime stays, only the options change
+            keep = True
+            continue
         k, v = kv.split("=")
         wl.dl.set_option(k, int(v))
-    wl.dl.set_option("drop_scratch", 1)
+    if not keep:
+        wl.dl.set_option("drop_scratch", 1)
     for _ in range(3):
         wl.step()
     torch.cuda.synchronize()

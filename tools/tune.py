@@ -49,7 +49,7 @@ def main():
         for v in variants:
             wl.dl.set_option("variant", specs[v][0])
             wl.dl.set_option("dbg", 0)
-            for k in ("cuckoo", "dense", "tag_sub", "direct", "six_byte"):          # (place_trials is per context: --opts place_trials=1 turns the trials off)          # per-variant toggles start from their defaults
+            for k in ("cuckoo", "dense", "tag_sub", "direct", "six_byte", "five_byte"):          # (place_trials is per context: --opts place_trials=1 turns the trials off)          # per-variant toggles start from their defaults
                 wl.dl.set_option(k, 1)
             for k, val in specs[v][1]:
                 wl.dl.set_option(k, int(val))
