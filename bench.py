@@ -58,6 +58,7 @@ def parse_args(argv=None):
     ap.add_argument("--e2e-reads", type=int, default=100_000_000, help="reads of the end-to-end FASTQ leg; 0 disables it")
     ap.add_argument("--e2e-gz-reads", type=int, default=10_000_000, help="reads of the .gz end-to-end leg; 0 disables it")
     ap.add_argument("--e2e-dir", default=None, help="where the FASTQ text is written (default: /dev/shm or /tmp)")
+    ap.add_argument("--placement-trials", type=int, default=1, help="0: skip the second timed region that prices the opt-in placement trials (profiling runs)")
     return ap.parse_args(argv)
 
 
@@ -511,7 +512,7 @@ def main():
     # block pool and keep the fastest.  Priced separately: the same K steps again with the trials on, their one-off cost,
     # and the memory they held meanwhile.
     placement = None
-    if args.reads >= (1 << 25):
+    if args.reads >= (1 << 25) and args.placement_trials:
         import ctypes as C
         wl.dl.set_option("place_trials", 32)
         fence()

@@ -85,6 +85,12 @@ int sgc_device_count(void);
 int sgc_init(int device, sgc_ctx **out);
 void sgc_free(sgc_ctx *);
 
+/* A second ctx on the same device that SHARES the library tables of `src` (built once, read-only afterwards; reference
+ * src/count.rs:103-136: one Library and one Permuter lent to every rayon worker) and has its own stream, scratch buffers and
+ * samples: what a host with several worker threads per GPU uses instead of building the same tables once per worker.  The
+ * tables live until the last ctx that shares them is freed or given another library. */
+int sgc_ctx_clone(sgc_ctx *src, sgc_ctx **out);
+
 /* Run everything on a caller-supplied hipStream_t instead of the ctx's own.  A NULL stream is the HIP
  * legacy default stream, exactly as hipStream_t 0 is; SGC_STREAM_OWN returns to the ctx's own stream. */
 #define SGC_STREAM_OWN ((void *)(intptr_t)-1)

@@ -35,6 +35,7 @@ SYMBOLS = {
     "sgc_device_count": (_i, []),
     "sgc_init": (_i, [_i, C.POINTER(_vp)]),
     "sgc_free": (None, [_vp]),
+    "sgc_ctx_clone": (_i, [_vp, C.POINTER(_vp)]),
     "sgc_set_stream": (_i, [_vp, _vp]),
     "sgc_get_stream": (_vp, [_vp]),
     "sgc_set_library": (_i, [_vp, _u8p, _u32, _u32, _i]),

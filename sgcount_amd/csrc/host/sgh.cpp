@@ -913,20 +913,45 @@ void count(const CountOptions &opt_in) {
     flat.reserve(library.seqs.size() * library.size);
     for (const auto &s : library.seqs) flat += s;
     std::vector<sgc_ctx *> ctxs;
-    struct CtxGuard { std::vector<sgc_ctx *> &v; ~CtxGuard() { for (auto c : v) sgc_free(c); } } cg{ctxs};
+    struct CtxGuard { std::vector<sgc_ctx *> &v; ~CtxGuard() { for (auto c : v) if (c) sgc_free(c); } } cg{ctxs};
     std::vector<int> ctx_dev;
     double init_s = 0;
-    for (size_t k = 0; k < n_ctx; k++) {
+    // Library + Permuter are built ONCE per device (count.rs:103-107 builds them once and lends them to every rayon worker):
+    // one thread per device builds its tables — the devices in parallel —, and the other contexts of a device (worker threads
+    // beyond the number of GPUs) are clones that share those tables (sgc_ctx_clone).
+    const size_t n_primary = std::min(n_ctx, (size_t)n_dev);
+    ctxs.assign(n_ctx, nullptr);
+    for (size_t k = 0; k < n_ctx; k++) ctx_dev.push_back((int)(k % (size_t)n_dev));
+    std::vector<double> dev_init_s(n_primary, 0.0), dev_build_s(n_primary, 0.0);
+    std::vector<std::string> build_err(n_primary);
+    std::vector<int> build_rc(n_primary, SGC_OK);
+    if (!opt.quiet && !opt.exact) fprintf(stderr, "Generating Mismatch Library\n");
+    auto build_on = [&](size_t d) {
+        const double t0 = now_s();
         sgc_ctx *c = nullptr;
-        const double t_i0 = now_s();
-        sgc_check(sgc_init((int)(k % (size_t)n_dev), &c), "sgc_init");
-        init_s += now_s() - t_i0;
-        ctxs.push_back(c);
-        ctx_dev.push_back((int)(k % (size_t)n_dev));
-        if (!opt.quiet && !opt.exact && k == 0) fprintf(stderr, "Generating Mismatch Library\n");
-        sgc_check(sgc_set_library(c, (const uint8_t *)flat.data(), (uint32_t)library.seqs.size(), (uint32_t)library.size,
-                                  !opt.exact), "sgc_set_library");
-        if (!opt.quiet && !opt.exact && k == 0) fprintf(stderr, "Finished Mismatch Library\n");
+        int rc = sgc_init((int)d, &c);
+        dev_init_s[d] = now_s() - t0;
+        if (rc == SGC_OK) {
+            ctxs[d] = c;
+            rc = sgc_set_library(c, (const uint8_t *)flat.data(), (uint32_t)library.seqs.size(), (uint32_t)library.size, !opt.exact);
+        }
+        if (rc != SGC_OK) { build_rc[d] = rc; build_err[d] = std::string(ctxs[d] ? "sgc_set_library: " : "sgc_init: ") + sgc_last_error(); }
+        dev_build_s[d] = now_s() - t0 - dev_init_s[d];
+    };
+    {
+        std::vector<std::thread> builders;
+        for (size_t d = 1; d < n_primary; d++) builders.emplace_back(build_on, d);
+        build_on(0);
+        for (auto &t : builders) t.join();
+    }
+    for (size_t d = 0; d < n_primary; d++) {
+        init_s += dev_init_s[d];
+        if (build_rc[d] == SGC_E_DUPLICATE) throw Panic(build_err[d]);
+        if (build_rc[d] != SGC_OK) throw Error(build_err[d]);
+    }
+    for (size_t k = n_primary; k < n_ctx; k++) sgc_check(sgc_ctx_clone(ctxs[k % (size_t)n_dev], &ctxs[k]), "sgc_ctx_clone");
+    if (!opt.quiet && !opt.exact) fprintf(stderr, "Finished Mismatch Library\n");
+    for (sgc_ctx *c : ctxs) {
         if (!opt.stats_path.empty()) sgc_check(sgc_timing_enable(c, 1), "sgc_timing_enable");
         sgc_check(sgc_set_option(c, "batch_records", (int64_t)(16 * SCAN_BUF_RECORDS)), "sgc_set_option");     // a whole number of pinned buffers
     }
@@ -981,11 +1006,13 @@ void count(const CountOptions &opt_in) {
     if (!opt.stats_path.empty()) {
         FILE *f = fopen(opt.stats_path.c_str(), "wb");
         if (!f) throw Error("cannot create the stats file: " + opt.stats_path);
+        std::string per_dev;
+        for (size_t d = 0; d < dev_build_s.size(); d++) { char b[48]; snprintf(b, sizeof(b), "%s%.6f", d ? ", " : "", dev_build_s[d]); per_dev += b; }
         fprintf(f, "{\"library_load_s\": %.6f, \"table_build_s\": %.6f, \"samples_s\": %.6f, \"table_write_s\": %.6f, \"total_s\": %.6f, "
                    "\"device_init_s\": %.6f, \"context_free_s\": %.6f, \"count_entered_unix_s\": %.6f, \"stats_written_unix_s\": %.6f, "
-                   "\"devices\": %d, \"contexts\": %zu, \"worker_threads\": %zu, \"samples\": [",
+                   "\"devices\": %d, \"contexts\": %zu, \"worker_threads\": %zu, \"table_build_per_device_s\": [%s], \"samples\": [",
                 t_lib - t_start, t_tables - t_lib, t_counted - t_tables, t_end - t_counted, t_end - t_start, init_s, t_freed - t_end, t_start_unix, unix_s(),
-                n_dev, n_ctx, n_threads);
+                n_dev, n_ctx, n_threads, per_dev.c_str());
         for (size_t i = 0; i < n; i++) {
             const SampleStats &x = stats[i];
             fprintf(f, "%s{\"device\": %d, \"reads\": %llu, \"text_bytes\": %llu, \"gz\": %s, \"bgzf\": %s, \"text_path\": %s, \"scan_path\": %s, \"host_copy_s\": %.6f, \"reader_threads\": %zu, "

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -44,8 +45,16 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 enum { T_LOOKUP = 0, T_HIST = 1, T_PACK = 2, T_PART = 3, T_MISS = 4, T_H2D = 5, T_KINDS = 6 };
 
+// Device memory of one library's tables, shared by a ctx and its clones (read-only once built)
+struct table_owner {
+    int device = 0;
+    std::vector<void *> ptrs;
+    ~table_owner() { (void)hipSetDevice(device); for (void *p : ptrs) (void)hipFree(p); }
+};
+
 struct sgc_ctx {
     int device = 0;
+    std::shared_ptr<table_owner> tables;
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t side_stream = nullptr;          // k_generic runs beside k_resolve_miss (fork/join with events)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -519,37 +528,42 @@ int sgc_init(int device, sgc_ctx **out) {
     return SGC_OK;
 }
 
+// every device allocation that belongs to the library tables of a ctx
+static std::vector<void *> table_ptrs(const sgc_ctx *c) {
+    std::vector<void *> v = {c->d_lib_slots, c->d_lib_cuckoo, c->d_perm_slots, c->d_lib_vals, c->d_perm_vals, c->d_bloom_lib, c->d_bloom_perm,
+                             c->d_amb, c->d_core_filt, c->d_bytes_seqs, c->d_bytes_pl};
+    for (int k = 0; k < 2; k++) {
+        v.push_back(c->d_core_ents[k]); v.push_back(c->d_core_gids[k]); v.push_back(c->d_core_starts[k]);
+        v.push_back(c->d_bytes_tags[k]); v.push_back(c->d_bytes_vals[k]);
+    }
+    v.erase(std::remove(v.begin(), v.end(), nullptr), v.end());
+    return v;
+}
+
 static void free_tables(sgc_ctx *c) {
-    if (c->d_lib_slots) hipFree(c->d_lib_slots);
-    if (c->d_lib_cuckoo) hipFree(c->d_lib_cuckoo);
+    // a finished library belongs to its owner token, shared with the clones of the ctx (sgc_ctx_clone): the last one frees it;
+    // a half-built one (error paths of sgc_set_library) is freed here
+    if (c->tables) c->tables.reset();
+    else for (void *p : table_ptrs(c)) hipFree(p);
     c->d_lib_cuckoo = nullptr;
-    if (c->d_perm_slots) hipFree(c->d_perm_slots);
-    if (c->d_lib_vals) hipFree(c->d_lib_vals);
-    if (c->d_perm_vals) hipFree(c->d_perm_vals);
-    if (c->d_bloom_lib) hipFree(c->d_bloom_lib);
-    if (c->d_bloom_perm) hipFree(c->d_bloom_perm);
     c->d_bloom_lib = c->d_bloom_perm = nullptr;
     for (int k = 0; k < 2; k++) {
-        if (c->d_core_ents[k]) hipFree(c->d_core_ents[k]);
-        if (c->d_core_gids[k]) hipFree(c->d_core_gids[k]);
-        if (c->d_core_starts[k]) hipFree(c->d_core_starts[k]);
         c->d_core_ents[k] = nullptr; c->d_core_gids[k] = nullptr; c->d_core_starts[k] = nullptr; c->v_core[k] = sgc_core_view{};
     }
-    if (c->d_amb) hipFree(c->d_amb);
-    if (c->d_core_filt) hipFree(c->d_core_filt);
     c->d_amb = nullptr; c->d_core_filt = nullptr; c->has_core = false;
-    if (c->d_bytes_seqs) hipFree(c->d_bytes_seqs);
-    if (c->d_bytes_pl) hipFree(c->d_bytes_pl);
-    for (int k = 0; k < 2; k++) {
-        if (c->d_bytes_tags[k]) hipFree(c->d_bytes_tags[k]);
-        if (c->d_bytes_vals[k]) hipFree(c->d_bytes_vals[k]);
-        c->d_bytes_tags[k] = nullptr; c->d_bytes_vals[k] = nullptr;
-    }
+    for (int k = 0; k < 2; k++) { c->d_bytes_tags[k] = nullptr; c->d_bytes_vals[k] = nullptr; }
     c->d_bytes_seqs = nullptr; c->d_bytes_pl = nullptr; c->bytes_mode = false; c->v_bytes = sgc_bytes_view{};
     c->b_lib = sgc_bloom_view{}; c->b_perm = sgc_bloom_view{};
     c->d_lib_slots = c->d_perm_slots = nullptr;
     c->d_lib_vals = c->d_perm_vals = nullptr;
     c->has_lib = false;
+}
+
+// the library of the ctx is complete: hand its allocations to an owner token
+static void adopt_tables(sgc_ctx *c) {
+    auto t = std::make_shared<table_owner>();
+    t->device = c->device; t->ptrs = table_ptrs(c);
+    c->tables = std::move(t);
 }
 
 void sgc_free(sgc_ctx *c) {
@@ -575,6 +589,37 @@ void sgc_free(sgc_ctx *c) {
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
+}
+
+int sgc_ctx_clone(sgc_ctx *src, sgc_ctx **out) {
+    if (!src || !out) return fail(SGC_E_ARG, "sgc_ctx_clone: NULL argument");
+    *out = nullptr;
+    if (!src->has_lib || !src->tables) return fail(SGC_E_STATE, "sgc_ctx_clone: the source ctx has no library");
+    sgc_ctx *c = nullptr;
+    const int rc = sgc_init(src->device, &c);
+    if (rc) return rc;
+    // the tables (shared, read-only) and everything that describes them; streams, scratch and samples are the clone's own
+    c->tables = src->tables;
+    c->has_lib = src->has_lib; c->one_mm = src->one_mm; c->rec16 = src->rec16; c->n = src->n; c->L = src->L;
+    c->d_lib_slots = src->d_lib_slots; c->d_perm_slots = src->d_perm_slots; c->d_lib_cuckoo = src->d_lib_cuckoo;
+    c->d_lib_vals = src->d_lib_vals; c->d_perm_vals = src->d_perm_vals;
+    c->v_lib = src->v_lib; c->v_perm = src->v_perm;
+    c->d_bloom_lib = src->d_bloom_lib; c->d_bloom_perm = src->d_bloom_perm; c->b_lib = src->b_lib; c->b_perm = src->b_perm;
+    c->perm_entries = src->perm_entries;
+    c->has_core = src->has_core; c->d_amb = src->d_amb; c->d_core_filt = src->d_core_filt;
+    for (int k = 0; k < 2; k++) {
+        c->d_core_ents[k] = src->d_core_ents[k]; c->d_core_gids[k] = src->d_core_gids[k]; c->d_core_starts[k] = src->d_core_starts[k];
+        c->v_core[k] = src->v_core[k];
+        c->d_bytes_tags[k] = src->d_bytes_tags[k]; c->d_bytes_vals[k] = src->d_bytes_vals[k];
+    }
+    c->bytes_mode = src->bytes_mode; c->d_bytes_seqs = src->d_bytes_seqs; c->d_bytes_pl = src->d_bytes_pl; c->v_bytes = src->v_bytes;
+    // and the options that shape the passes
+    c->variant = src->variant; c->per_lane = src->per_lane; c->k1_wgs = src->k1_wgs; c->max_chunk = src->max_chunk;
+    c->batch_records = src->batch_records; c->dense = src->dense; c->direct = src->direct; c->six_byte = src->six_byte;
+    c->five_byte = src->five_byte; c->tag_sub = src->tag_sub; c->use_cuckoo = src->use_cuckoo; c->place_trials = src->place_trials;
+    c->verbose = src->verbose;
+    *out = c;
+    return SGC_OK;
 }
 
 int sgc_set_stream(sgc_ctx *c, void *hip_stream) {
@@ -715,6 +760,7 @@ static int set_library_bytes(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32
     c->perm_entries = hb.perm_entries;
     c->bytes_mode = true;
     c->n = n; c->L = L; c->one_mm = one_mm; c->rec16 = false; c->has_lib = true;
+    adopt_tables(c);
     return SGC_OK;
 }
 
@@ -853,6 +899,7 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
         }
     }
     c->n = n; c->L = L; c->one_mm = enable_1mm != 0; c->rec16 = L > SGC_REC8_MAXL; c->has_lib = true;
+    adopt_tables(c);
     return SGC_OK;
 }
 

@@ -85,3 +85,38 @@ def test_cli_two_samples_over_two_devices(tmp_path):
         want, _, _ = O.count_text(lib_text, t, False, 30, False, True)
         for g, c in enumerate(want):
             assert got.get("sg%06d" % g, [0] * 4)[i] == c
+
+
+def test_cli_workers_on_one_device_share_one_table_set(tmp_path):
+    """`-t 4` on one GPU: four contexts, ONE table build (the others are clones that share the device's tables — the reference
+    builds Library and Permuter once and lends them to every rayon worker, count.rs:103-136).  The set-up of four contexts
+    must not cost four table builds: less than 1.5x the set-up of one (it was 4x), and the table is the oracle's."""
+    from sgcount_amd import hostlib, synth
+    lib = synth.library(100_000, 20)
+    lib_text = synth.library_fasta(lib)
+    lp = str(tmp_path / "lib.fa")
+    open(lp, "wb").write(lib_text)
+    paths, texts = [], []
+    for i in range(4):
+        t = synth.fastq_host(lib, 0, 20000 + 500 * i, seed=synth.READS_SEED + i)
+        p = str(tmp_path / ("s%d.fastq" % i))
+        open(p, "wb").write(t)
+        paths.append(p); texts.append(t)
+    out, stats = str(tmp_path / "out.tsv"), str(tmp_path / "stats.json")
+
+    def run(threads):
+        p = subprocess.run([hostlib.cli_path(), "-l", lp, "-i", *paths, "-a", "30", "-q", "-t", str(threads), "--devices", "1", "-o", out,
+                            "--stats-json", stats], capture_output=True, timeout=300)
+        assert p.returncode == 0, p.stderr.decode()
+        return json.load(open(stats))
+    run(1)                                             # warm the page cache / the device
+    one = min((run(1) for _ in range(2)), key=lambda s: s["table_build_s"])
+    four = min((run(4) for _ in range(2)), key=lambda s: s["table_build_s"])
+    assert one["contexts"] == 1 and four["contexts"] == 4 and four["devices"] == 1
+    assert len(four["table_build_per_device_s"]) == 1
+    assert four["table_build_s"] < 1.5 * one["table_build_s"] + 0.05, (one["table_build_s"], four["table_build_s"])
+    rows = [ln.split("\t") for ln in open(out).read().splitlines()[1:]]
+    got = {r[0]: [int(x) for x in r[1:]] for r in rows}
+    want0, _, _ = O.count_text(lib_text, texts[0], False, 30, False, True)
+    for g, c in enumerate(want0):
+        assert got.get("sg%06d" % g, [0] * 4)[0] == c

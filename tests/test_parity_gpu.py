@@ -435,3 +435,45 @@ def test_async_packed_pushes_are_batched_on_the_device(S):
     finally:
         ffi.check(L.sgc_set_option(dev.ctx, b"batch_records", 1 << 24))
         L.sgc_free_pinned(pinned)
+
+
+def test_cloned_context_shares_the_tables(S):
+    """sgc_ctx_clone: a second ctx on the same device with its own stream and scratch but the SAME library tables (the reference
+    lends one Library / Permuter to all its rayon workers, count.rs:103-136).  The clone counts the oracle's table, also after the
+    source ctx has been freed, and a clone of a ctx without a library is refused."""
+    import ctypes as C
+    rng = random.Random(23)
+    guides, reads = _random_case(rng, 20, 300, 20000, 4)
+    lib = _lib(S, _fasta(guides))
+    ffi = S._ffi
+    L = ffi.load()
+    want, tot, mat = O.count_text(_fasta(guides), _reads_fasta(reads), False, 4, False, True)
+    recs = S.pack_reads_host(reads, 20, S.Offset.Forward(4), True)
+    flat = b"".join(guides)
+    src, bare, clone = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    ffi.check(L.sgc_init(0, C.byref(bare)))
+    assert L.sgc_ctx_clone(bare, C.byref(clone)) == ffi.E_STATE
+    L.sgc_free(bare)
+    ffi.check(L.sgc_init(0, C.byref(src)))
+    ffi.check(L.sgc_set_library(src, flat, len(guides), 20, 1))
+    ffi.check(L.sgc_ctx_clone(src, C.byref(clone)))
+
+    def count(ctx):
+        smp = C.c_void_p()
+        ffi.check(L.sgc_sample_begin(ctx, C.byref(smp), 0, 4, 1))
+        ffi.check(L.sgc_sample_push_packed(smp, recs.ctypes.data, len(reads), ffi.MEM_HOST))
+        out = np.zeros(len(guides), dtype=np.uint64)
+        t, m = C.c_uint64(), C.c_uint64()
+        ffi.check(L.sgc_sample_finish(smp, out.ctypes.data, C.byref(t), C.byref(m)))
+        L.sgc_sample_free(smp)
+        return out.tolist(), t.value, m.value
+
+    assert count(clone) == (want, tot, mat) and count(src) == (want, tot, mat)
+    info = ffi.LibInfo()
+    ffi.check(L.sgc_library_info(clone, C.byref(info)))
+    assert info.n_guides == len(guides) and info.one_mismatch == 1
+    L.sgc_free(src)                                   # the tables live on with the clone
+    assert count(clone) == (want, tot, mat)
+    ffi.check(L.sgc_set_library(clone, flat, len(guides), 20, 0))      # a new library on the clone: the shared tables are released
+    assert count(clone)[0] == O.count_text(_fasta(guides), _reads_fasta(reads), False, 4, True, True)[0]
+    L.sgc_free(clone)
