@@ -74,6 +74,14 @@ typedef struct {
     uint64_t core_partitions;  /* partitions of each core index of the in-LDS resolver (also built for exact
                                   mode, where one exact-only pass uses it); 0 = no core index (L outside 4..23, split-layout
                                   table, or the guides do not spread): probing resolver */
+    uint32_t path;             /* which count path serves this library with the default options — the fallbacks are results-preserving but
+                                  not equally fast: 4 = partitioned pass + in-LDS core resolver (the shipped path: L <= 23,
+                                  <= 128 slices = ~210k guides); 3 = partitioned pass + probing resolver (no core index); 1 = guide-id
+                                  array + LDS histogram (two-word records, split-layout tables, more than 128 slices); 0 = byte-string
+                                  path (record_bytes == 0) */
+    uint32_t slices;           /* library slices of the partitioned pass (0 if path < 3); 64 at 100k guides; 128 costs ~35 % */
+    uint32_t slice_record_bytes; /* bytes of a clean record inside a slice block: 5, 6 or 8 (0 if path < 3) */
+    uint32_t reserved_;
 } sgc_lib_info;
 
 /* ---- context: device + library tables -------------------------------------------------------- */

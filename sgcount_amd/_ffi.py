@@ -26,7 +26,8 @@ class Timing(C.Structure):
 class LibInfo(C.Structure):
     _fields_ = [("n_guides", C.c_uint32), ("guide_len", C.c_uint32), ("record_bytes", C.c_uint32),
                 ("one_mismatch", C.c_uint32), ("lib_slots", C.c_uint64), ("perm_slots", C.c_uint64),
-                ("perm_entries", C.c_uint64), ("table_bytes", C.c_uint64), ("core_partitions", C.c_uint64)]
+                ("perm_entries", C.c_uint64), ("table_bytes", C.c_uint64), ("core_partitions", C.c_uint64),
+                ("path", C.c_uint32), ("slices", C.c_uint32), ("slice_record_bytes", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 # every symbol include/sgcount_hip.h declares: name -> (restype, argtypes)

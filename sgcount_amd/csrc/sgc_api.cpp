@@ -920,6 +920,17 @@ int sgc_library_info(sgc_ctx *c, sgc_lib_info *out) {
     out->lib_slots = 1ull << c->v_lib.log2_slots;
     out->perm_slots = c->one_mm ? 1ull << c->v_perm.log2_slots : 0;
     out->perm_entries = c->perm_entries;
+    if (sgc_part_supported(c->v_lib, c->rec16)) {
+        out->path = c->has_core ? 4 : 3;
+        out->slices = 1u << (c->v_lib.log2_slots - c->v_lib.log2_slice);
+        // as count_records decides (default options): five-byte, six-byte or whole records in the slice blocks
+        const int sub = c->has_core ? (int)c->v_core[0].log2_p - (int)(c->v_lib.log2_slots - c->v_lib.log2_slice) : -1;
+        const bool direct = c->has_core && c->v_lib.core_cl == c->v_core[0].cl && c->v_lib.log2_slice < c->v_lib.log2_slots && sub >= 0 && sub <= 2;
+        const uint32_t sb = c->v_lib.log2_slots - c->v_lib.log2_slice;
+        out->slice_record_bytes = !direct ? 8 : (2u * (c->L + 2u) - sb <= 40u && sb + (uint32_t)sub <= 2u * c->v_lib.core_cl) ? 5 : (2u * (c->L + 2u) + 2u <= 48u) ? 6 : 8;
+    } else {
+        out->path = 1;
+    }
     const uint64_t per = c->v_lib.gid_bits ? 8 : 12;
     out->table_bytes = (out->lib_slots + out->perm_slots) * per + (c->d_lib_cuckoo ? out->lib_slots * 8 : 0);
     if (c->has_core) {

@@ -244,6 +244,15 @@ __global__ void __launch_bounds__(FQ_THREADS, 8) __attribute__((amdgpu_num_sgpr(
         rhi = seq_lines_before(ph, l1 + 1u < n_lines ? l1 + 1u : n_lines);
     }
     if (SGC_DBG(a.dbg, 2u)) return;
+    // Reverse strand: a sequence line is listed by the newline that CLOSES it, so a stream that breaks off inside a sequence line
+    // (its last line has no '\n': a truncated record, which the host reports from the line count) would leave that record's slot
+    // unwritten although it is counted — it gets the all-dead record (as k_fastq_lines does).
+    if (a.reverse && tile == a.tiles - 1u && t == 0 && n_lines > a.tile_base[a.tiles] && ((ph + n_lines - 1u) & 3u) == 1u) {
+        const uint64_t r = seq_lines_before(ph, n_lines - 1u), K = a.L + 2u;
+        const uint64_t dead = SGC_STATE_DEAD * (1u + K + K * K);
+        if (REC16) { a.recs[2 * r] = 0; a.recs[2 * r + 1] = dead; }
+        else a.recs[r] = dead << (2 * K);
+    }
     for (uint32_t rb = rlo; rb < rhi || rb == rlo; rb += FQ_CAP) {
         // list the owned sequence lines [rb, rb + FQ_CAP): forward = stage offset of the line start, reverse = of its '\n'
         uint64_t mm = mine;

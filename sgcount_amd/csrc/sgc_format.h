@@ -129,13 +129,44 @@ SGC_HD uint32_t sgc_rest_hash(uint32_t rest, uint32_t log2_bits) { return (rest 
 // that sits in a slice's block need not store the slice bits: the five-byte slice records of k_partition keep the remaining
 // 2 cl - (slice bits) bits of the mixed value in place of the core bases and k_count_slices rebuilds the core value with one
 // multiply.  One multiply to evaluate (the partition kernel does it for every read, and 32-bit multiplies run at quarter rate).
+// low 32 bits of (a mod 2^24) * (b mod 2^24): v_mul_u32_u24 on the device — full rate, where a 32-bit multiply runs at a quarter
+SGC_HD uint32_t sgc_mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return (a & 0xFFFFFFu) * (b & 0xFFFFFFu);
+#endif
+}
+// the same with a compile-time multiplier, as an instruction the compiler cannot "improve": it folds a later shift or mask into the
+// constant of a known-small product, the constant outgrows 24 bits and the multiply falls back to the quarter-rate 32-bit one
+template <uint32_t C> SGC_HD uint32_t sgc_mul24c(uint32_t a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %2, %1" : "=v"(r) : "v"(a), "n"(C & 0xFFFFFFu));
+    return r;
+#else
+    return (a & 0xFFFFFFu) * (C & 0xFFFFFFu);
+#endif
+}
 #define SGC_CORE_M1 0x9E3779B1u
 #define SGC_CORE_M1_INV 0x0E8B2F51u      // SGC_CORE_M1 * SGC_CORE_M1_INV == 1 (mod 2^32), hence modulo every 2^k
-SGC_HD uint32_t sgc_core_mix(uint32_t corev, uint32_t cl) { return (corev * SGC_CORE_M1) & (uint32_t)((1ull << (2 * cl)) - 1ull); }
-SGC_HD uint32_t sgc_core_unmix(uint32_t h, uint32_t cl) { return (h * SGC_CORE_M1_INV) & (uint32_t)((1ull << (2 * cl)) - 1ull); }
-SGC_HD uint32_t sgc_core_hash(uint32_t corev, uint32_t cl) { return (corev * SGC_CORE_M1) << (32 - 2 * cl); }
-// 32-bit hash of a whole key, for the bucket inside a core-hashed slice (one multiply instead of the 64-bit sgc_hash)
-SGC_HD uint32_t sgc_hash32(uint64_t key) { return (uint32_t)(key ^ (key >> 29)) * 0x85EBCA6Bu; }
+// (the low 2 cl bits of a product depend only on the low 2 cl bits of its factors: for 2 cl <= 24 — every one-word record,
+// L <= 23 — the 24-bit multiply gives the same bits)
+SGC_HD uint32_t sgc_core_mix(uint32_t corev, uint32_t cl) {
+    const uint32_t m = (uint32_t)((1ull << (2 * cl)) - 1ull);
+    return (cl <= 12 ? sgc_mul24c<SGC_CORE_M1>(corev) : corev * SGC_CORE_M1) & m;
+}
+SGC_HD uint32_t sgc_core_unmix(uint32_t h, uint32_t cl) {
+    const uint32_t m = (uint32_t)((1ull << (2 * cl)) - 1ull);
+    return (cl <= 12 ? sgc_mul24c<SGC_CORE_M1_INV>(h) : h * SGC_CORE_M1_INV) & m;
+}
+SGC_HD uint32_t sgc_core_hash(uint32_t corev, uint32_t cl) { return sgc_core_mix(corev, cl) << (32 - 2 * cl); }
+// 32-bit hash of a whole key (<= 48 bits: one-word records), for the slot inside a core-hashed slice: two full-rate 24-bit
+// multiplies, one per half of the key, instead of the 64-bit sgc_hash.  Its top bits pick the slot, the bits below them the
+// displacement to the key's alternate slot (sgc_cuckoo_alt) — k_count_slices evaluates both for every read.
+SGC_HD uint32_t sgc_hash32(uint64_t key) {
+    return sgc_mul24c<0x9E3779u>((uint32_t)key) + sgc_mul24c<0xC2B2AFu>((uint32_t)(key >> 24));
+}
 SGC_HD uint32_t sgc_core_part(uint32_t h, uint32_t log2_p) { return log2_p ? h >> (32 - log2_p) : 0u; }
 // the same from the mixed value alone (needs log2_p <= 2 cl)
 SGC_HD uint32_t sgc_core_part_mix(uint32_t mix, uint32_t cl, uint32_t log2_p) { return mix >> (2 * cl - log2_p); }
@@ -161,12 +192,13 @@ SGC_HD uint32_t sgc_home_slot_ex(uint64_t key, uint32_t log2_slots, uint32_t log
 // no loop at all (the open-addressed layout needs one for full buckets, and its exec-mask bookkeeping was most of that
 // kernel's scalar instruction stream).  The table is built at load <= 0.4, below the 0.5 threshold of two-choice cuckoo
 // placement with one-slot buckets.  ls = log2(slots per slice).
-SGC_HD uint32_t sgc_cuckoo_alt(uint64_t key, uint32_t s1, uint32_t ls) {
+SGC_HD uint32_t sgc_cuckoo_alt_h(uint32_t h32 /* sgc_hash32(key) */, uint32_t s1, uint32_t ls) {
     if (ls == 0) return s1;
-    uint32_t d = ((uint32_t)(key >> 3) * 0xC2B2AE35u) >> (32 - ls);
+    uint32_t d = (h32 << ls) >> (32 - ls);          // the ls bits below the slot bits
     d |= (uint32_t)(d == 0);
     return s1 ^ d;
 }
+SGC_HD uint32_t sgc_cuckoo_alt(uint64_t key, uint32_t s1, uint32_t ls) { return sgc_cuckoo_alt_h(sgc_hash32(key), s1, ls); }
 SGC_HD uint32_t sgc_core_home(uint32_t h, uint32_t log2_p) {
     return (h >> (32 - log2_p - SGC_CORE_LOG2_S)) & ((1u << SGC_CORE_LOG2_S) - 1u);
 }

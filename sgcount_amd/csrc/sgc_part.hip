@@ -303,16 +303,23 @@ __device__ __forceinline__ uint64_t k2_record(const uint64_t *__restrict__ pool,
 // REC (with DIRECT): 1 = the slice blocks hold six-byte records (k_partition, P6_HI_OFF), 2 = five-byte records: a record is
 // its span with the core-A bases replaced by the mixed core value below the slice index; the span comes back with one multiply
 // (sgc_core_unmix) — this kernel waits for its pool bytes, not for its arithmetic.
-template <int LOG2_SLICE, bool CUCKOO, bool DENSE, bool DIRECT, int REC>
+// LT: 20 = the geometry of a 20-base library with 64 full slices as compile-time constants (guide length, core length 9, six slice
+// bits, two sub-partition bits): the record decode and the probe become shifts and masks by immediates instead of 64-bit shifts
+// by scalars — the loop of this kernel is as much vector issue as it is memory; 0 = everything from the arguments.
+template <int LOG2_SLICE, bool CUCKOO, bool DENSE, bool DIRECT, int REC, int LT = 0>
 __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(80))) k_count_slices(uint64_t *__restrict__ pool, uint32_t *__restrict__ desc,
                                                              const uint32_t *__restrict__ wcnt, const uint32_t *__restrict__ wlist,
-                                                             uint32_t k1_wgs, uint32_t blocks_per_wg, uint32_t G, uint32_t L,
+                                                             uint32_t k1_wgs, uint32_t blocks_per_wg, uint32_t G, uint32_t L_arg,
                                                              sgc_table_view lib, uint32_t *__restrict__ counts,
                                                              unsigned long long *__restrict__ matched, uint32_t dbg,
                                                              const sgc_runs ep, const uint64_t *__restrict__ cuck,
                                                              uint64_t *__restrict__ mrun, uint32_t *__restrict__ mcur) {
     constexpr uint32_t S = 1u << LOG2_SLICE;
     constexpr bool P6 = REC != 0;                            // packed slice blocks: no slot tag in the record, the key is hashed here
+    const uint32_t L = LT ? (uint32_t)LT : L_arg;
+    // (LT: the launcher checked that the arguments say the same)
+    const uint32_t core_cl = LT ? ((uint32_t)LT - 2u) / 2u : lib.core_cl, slice_bits = LT ? 6u : lib.log2_slots - lib.log2_slice;
+    const uint32_t sub_bits = LT ? 2u : ep.sub_bits;
     // A step of the workgroup takes BPS blocks side by side: lanes [h PART_BLOCK, (h + 1) PART_BLOCK) take record jl of the
     // h-th of them (h is wave-uniform: a block is a whole number of waves); a group is K2_U steps.
     static_assert(PART_BLOCK <= K2_THREADS && PART_BLOCK >= 64u, "a block is 1..16 waves of the workgroup");
@@ -328,11 +335,11 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     const uint32_t t = threadIdx.x, p = blockIdx.x / G, g = blockIdx.x % G;
     const uint32_t h = __builtin_amdgcn_readfirstlane(t / PART_BLOCK), jl = t % PART_BLOCK;
     const bool count_sub = ep.recs != nullptr && ep.sub_bits != 0xFFu;      // wave-uniform
-    const uint32_t slice = lib.log2_slice < (uint32_t)LOG2_SLICE ? (1u << lib.log2_slice) : S;   // small libraries
+    const uint32_t slice = (!LT && lib.log2_slice < (uint32_t)LOG2_SLICE) ? (1u << lib.log2_slice) : S;   // small libraries
     const uint32_t bmask = slice / 2 - 1u, gid_bits = lib.gid_bits;
     const uint64_t kmask = sgc_key_mask(L);
     const uint64_t *gslots = CUCKOO ? cuck : lib.slots;                // where the slice's slots (key << gid_bits | gid) live
-    const uint32_t ls = lib.log2_slice < (uint32_t)LOG2_SLICE ? lib.log2_slice : (uint32_t)LOG2_SLICE;   // log2 slots per slice
+    const uint32_t ls = (!LT && lib.log2_slice < (uint32_t)LOG2_SLICE) ? lib.log2_slice : (uint32_t)LOG2_SLICE;   // log2 slots per slice
     const uint64_t *tab1 = reinterpret_cast<const uint64_t *>(tab);                                       // the same keys, slot by slot
     const ulonglong2 *gtab = reinterpret_cast<const ulonglong2 *>(gslots) + (uint64_t)p * (slice / 2);
     for (uint32_t i = t; i < S / 2; i += K2_THREADS) {      // bare keys in LDS (a key is < 2^60, so SGC_EMPTY stays distinct)
@@ -359,7 +366,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     const uint32_t stretch = (s_hi - s_lo) * PART_BLOCK;           // no run can lack room: as long as all blocks of the share
     if (DENSE) {
         if (t < 4) wmiss4[t] = 0;
-        if (t == 0) { wmiss = 0; mbase = s_hi > s_lo ? atomicAdd(mcur, DIRECT ? stretch << ep.sub_bits : stretch) : 0u; }
+        if (t == 0) { wmiss = 0; mbase = s_hi > s_lo ? atomicAdd(mcur, DIRECT ? stretch << sub_bits : stretch) : 0u; }
         __syncthreads();
         run0 = mbase;
     }
@@ -415,22 +422,23 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 if (REC == 2) {
                     // five-byte record -> span: bits [0, 4) | core value << 4 | the rest above; the core value is the inverse of
                     // (slice index : kept bits) under the mixing multiply
-                    const uint32_t cb = 2u * lib.core_cl, kb = cb - (lib.log2_slots - lib.log2_slice);
+                    const uint32_t cb = 2u * core_cl, kb = cb - slice_bits;
                     const uint32_t raw_lo = (uint32_t)cur[q];
                     const uint32_t hmix = (p << kb) | ((raw_lo >> 4) & ((1u << kb) - 1u));
-                    const uint32_t corev = sgc_core_unmix(hmix, lib.core_cl);
+                    const uint32_t corev = sgc_core_unmix(hmix, core_cl);
                     cur[q] = (uint64_t)(raw_lo & 0xFu) | ((uint64_t)corev << 4) | ((cur[q] >> (4u + kb)) << (4u + cb)) |
-                             ((uint64_t)((hmix >> (kb - ep.sub_bits)) & ((1u << ep.sub_bits) - 1u)) << (2u * (L + 2u)));      // + the sub-partition where the six-byte record has it
+                             ((uint64_t)((hmix >> (kb - sub_bits)) & ((1u << sub_bits) - 1u)) << (2u * (L + 2u)));      // + the sub-partition where the six-byte record has it
                 }
                 const uint64_t key = (cur[q] >> 2) & kmask;
                 // home slot inside the slice: left there by k_partition, or (six-byte records) hashed again here
-                const uint32_t s1 = P6 ? sgc_hash32(key) >> (32u - ls) : (uint32_t)(cur[q] >> PART_TAG_SHIFT);
+                const uint32_t h32 = sgc_hash32(key);
+                const uint32_t s1 = P6 ? h32 >> (32u - ls) : (uint32_t)(cur[q] >> PART_TAG_SHIFT);
                 uint32_t b = s1 >> 1, slot;
                 ulonglong2 wv;
                 bool hit;
                 if (CUCKOO) {
                     // the key is in its home slot or in the alternate one: read both, no chain
-                    const uint32_t s2 = sgc_cuckoo_alt(key, s1, ls);
+                    const uint32_t s2 = sgc_cuckoo_alt_h(h32, s1, ls);
                     const uint64_t e1 = tab1[s1], e2 = tab1[s2];
                     const bool h2 = e2 == key;
                     hit = e1 == key || h2;
@@ -453,11 +461,11 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 atomicAdd(hv ? &cnt[slot] : &scratch[t & 63u], 1u);
                 // with K1's sub-partition tag the misses are counted by pass A's partition right here, and the epilogue's
                 // histogram sweep does not have to read the fronts once more
-                if (count_sub && !DIRECT) atomicAdd(mv ? &hn[(p << ep.sub_bits) | ((uint32_t)(cur[q] >> PART_SUB_SHIFT) & 3u)] : &scratch[t & 63u], 1u);
+                if (count_sub && !DIRECT) atomicAdd(mv ? &hn[(p << sub_bits) | ((uint32_t)(cur[q] >> PART_SUB_SHIFT) & 3u)] : &scratch[t & 63u], 1u);
                 if (DIRECT) {
                     const uint32_t sub = (uint32_t)(cur[q] >> (P6 ? 2u * (L + 2u) : PART_SUB_SHIFT)) & 3u;
                     const uint32_t pos = atomicAdd(mv ? &wmiss4[sub] : &scratch[64u + (t & 63u)], 1u);
-                    if (mv) mrun[(uint64_t)run0 + sub * stretch + pos] = cur[q] & (P6 ? (1ull << (2u * (L + 2u))) - 1ull : PART_TAG_MASK);
+                    if (mv) mrun[(uint64_t)run0 + sgc_mul24(sub, stretch) + pos] = cur[q] & (P6 ? (1ull << (2u * (L + 2u))) - 1ull : PART_TAG_MASK);
                 } else if (DENSE) {
                     // (a ballot + one atomic by the lowest missing lane measured 0.02 ms slower than this predicated add)
                     const uint32_t pos = atomicAdd(mv ? &wmiss : &scratch[64u + (t & 63u)], 1u);
@@ -599,10 +607,10 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
         __syncthreads();
         if (sweep == 0) run_reserve(ep, DIRECT ? G + blockIdx.x : blockIdx.x, hn, rcur, wtmp, &rbase);
     }
-    if (DIRECT && t < (1u << ep.sub_bits)) {
+    if (DIRECT && t < (1u << sub_bits)) {
         // the direct runs: row (p << sub_bits | sub) of the run matrices belongs to this slice alone, so its G workgroups take
         // columns 0 .. G - 1 of it (the generic shares follow from column G): no empty columns for the consumer to walk over
-        const uint32_t q = (p << ep.sub_bits) | t, c = wmiss4[t];
+        const uint32_t q = (p << sub_bits) | t, c = wmiss4[t];
         ep.cnt[(size_t)q * ep.W + g] = c;
         ep.off[(size_t)q * ep.W + g] = (uint32_t)(mrun - ep.recs) + run0 + t * stretch;
         if (c) atomicAdd(&ep.tot[q], c);
@@ -894,7 +902,12 @@ void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, c
     hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE, CK, DN, DR, REC>), dim3(g.partitions * G), dim3(K2_THREADS), 0, st, pool, desc, wcnt, wlist, \
                        g.k1_wgs, g.blocks_per_wg, G, L, lib, counts, matched, dbg, runs ? *runs : none, cuckoo, mrun, mcur)
     const int rec = direct ? slice_rec : 0;          // 0 = 8-byte, 1 = six-byte, 2 = five-byte slice blocks
-    if (cuckoo) { if (rec == 2) K2_LAUNCH(true, true, true, 2); else if (rec == 1) K2_LAUNCH(true, true, true, 1); else if (direct) K2_LAUNCH(true, true, true, 0); else if (dense) K2_LAUNCH(true, true, false, 0); else K2_LAUNCH(true, false, false, 0); }
+    const bool l20 = L == 20 && rec == 2 && cuckoo && lib.core_cl == 9 && lib.log2_slice == SGC_LDS_LOG2_SLICE &&
+                     lib.log2_slots == SGC_LDS_LOG2_SLICE + 6u && runs->sub_bits == 2;
+    if (l20)
+        hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE, true, true, true, 2, 20>), dim3(g.partitions * G), dim3(K2_THREADS), 0, st, pool, desc, wcnt, wlist,
+                           g.k1_wgs, g.blocks_per_wg, G, L, lib, counts, matched, dbg, *runs, cuckoo, mrun, mcur);
+    else if (cuckoo) { if (rec == 2) K2_LAUNCH(true, true, true, 2); else if (rec == 1) K2_LAUNCH(true, true, true, 1); else if (direct) K2_LAUNCH(true, true, true, 0); else if (dense) K2_LAUNCH(true, true, false, 0); else K2_LAUNCH(true, false, false, 0); }
     else { if (rec == 2) K2_LAUNCH(false, true, true, 2); else if (rec == 1) K2_LAUNCH(false, true, true, 1); else if (direct) K2_LAUNCH(false, true, true, 0); else if (dense) K2_LAUNCH(false, true, false, 0); else K2_LAUNCH(false, false, false, 0); }
 #undef K2_LAUNCH
 }

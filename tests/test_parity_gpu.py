@@ -303,12 +303,14 @@ def test_core_index_overflow_falls_back(S):
     lib_text, reads_text = _fasta(guides), _reads_fasta(reads)
     want, tot, mat = O.count_text(lib_text, reads_text, False, o, False, True)
     lib = _lib(S, lib_text)
-    assert lib.device(True).info().core_partitions == 0
+    info = lib.device(True).info()
+    assert info.core_partitions == 0 and info.path == 3 and info.slices >= 1         # the fallback is visible to the host
     ctr = S.Counter.new(S.parse_fastx(reads_text), lib, S.Permuter.new(lib.keys()), S.Offset.Forward(o), L, True, pack="device")
     assert ctr.guide_counts().tolist() == want and (ctr.total_reads(), ctr.matched_reads()) == (tot, mat)
     # an ordinary library of the same size gets its core index
     other = _lib(S, _fasta(_random_case(random.Random(3), L, 3000, 1, o)[0]))
-    assert other.device(True).info().core_partitions >= 1
+    info = other.device(True).info()
+    assert info.core_partitions >= 1 and info.path == 4
 
 
 def test_device_build_matches_host_build(S):

@@ -121,6 +121,7 @@ def test_large_library_128_slices(env, variant, ng):
     wl = workload.DeviceWorkload(n, ng, 20, one_mismatch=True, gen_chunk=700_000)
     info = wl.dl.info()
     assert info.lib_slots == 1 << 19 and info.core_partitions == (256 if ng == 150_000 else 512)
+    assert info.path == 4 and info.slices == 128 and info.slice_record_bytes == 5
     wl.dl.set_option("variant", variant)
     wl.step()
     counts, total, matched = wl.result()
