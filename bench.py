@@ -299,7 +299,8 @@ def e2e_block(wl, args, exact, cpu):
                                     "vs_cpu_setup_included": out["plain"]["reads_per_s"] / inc,
                                     "first_run_vs_cpu_setup_excluded": out["plain"]["reads_per_s_first_run"] / rate,
                                     "first_run_vs_cpu_setup_included": out["plain"]["reads_per_s_first_run"] / inc}
-        # .gz: one deflate stream is sequential — the run is bound by a single inflating core, whatever the GPU does
+        # .gz: one deflate stream — inflated by several threads (speculative chunk decoding, sgh_inflate.cpp); the CPU line next to
+        # it inflates on one thread like the reference (flate2 inside fxread on the sample's thread)
         ngz = min(args.e2e_gz_reads, n)
         if ngz > 0:
             t0 = time.perf_counter()
@@ -334,7 +335,8 @@ def e2e_block(wl, args, exact, cpu):
                         shutil.copyfileobj(part, o, 1 << 24)
                     os.remove("%s.%02d" % (gz, k))
             prep = time.perf_counter() - t0
-            wall_gz, stats = _run_cli(cli, base + ["-i", gz], stats=os.path.join(d, "stats_gz.json"))
+            gz_runs = [_run_cli(cli, base + ["-i", gz], stats=os.path.join(d, "stats_gz.json")) for _ in range(2)]
+            wall_gz, stats = min(gz_runs, key=lambda r: r[0])
             got = _table_counts(table, args.guides)
             wl.step(0, ngz)
             want_gz, total_gz, _ = wl.result()
@@ -359,9 +361,12 @@ def e2e_block(wl, args, exact, cpu):
             out["gz"] = {"reads": int(smp["reads"]), "gz_bytes": os.path.getsize(gz), "wall_s": wall_gz,
                          "reads_per_s": smp["reads"] / wall_gz, "table_equals_resident_pass": bool(np.array_equal(got, want_gz)) and
                          int(smp["reads"]) == total_gz, "sample_s": smp["wall_s"], "inflate_busy_s": smp["read_busy_s"],
-                         "zlib_inflate_alone_s": inflate_s, "prepare_s": prep,
-                         "note": "single-stream inflate bound: one core inflates at ~%.2f GB/s of text, the GPU side idles"
-                                 % (inflated / inflate_s / 1e9)}
+                         "zlib_inflate_alone_s": inflate_s, "prepare_s": prep, "wall_s_all_runs": [r[0] for r in gz_runs],
+                         "parallel_gzip": bool(smp.get("parallel_gzip")), "inflate_threads": smp["reader_threads"],
+                         "gzip_chunks_decoded_in_order": smp.get("gzip_chunks_decoded_in_order"),
+                         "note": "ONE deflate stream (16 members written by 16 gzip processes, no BGZF size fields): zlib on one core inflates "
+                                 "it at ~%.2f GB/s of text; here its chunks are decoded speculatively by %d threads and stitched in order"
+                                 % (inflated / inflate_s / 1e9, smp["reader_threads"])}
             if cpu:
                 r = smp["reads"]
                 cpu_gz = r / (inflate_s + r / cpu["value"])

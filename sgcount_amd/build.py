@@ -18,7 +18,7 @@ SO = os.path.join(PKG, "libsgcount_hip.so")
 SYNTH_SO = os.path.join(PKG, "libsgcount_synth.so")
 HOST_SO = os.path.join(PKG, "libsgcount_host.so")
 CLI = os.path.join(PKG, "bin", "sgcount-hip")
-HOST_SRCS = [os.path.join("host", f) for f in ("sgh.cpp", "sgh_scan.cpp", "sgh_cli.cpp", "sgh_capi.cpp")]
+HOST_SRCS = [os.path.join("host", f) for f in ("sgh.cpp", "sgh_scan.cpp", "sgh_inflate.cpp", "sgh_cli.cpp", "sgh_capi.cpp")]
 HOST_HDRS = [os.path.join("host", "sgh.hpp"), "sgc_format.h", os.path.join(INC, "sgcount_hip.h")]
 
 TARGETS = {
@@ -81,7 +81,7 @@ def build_host(force=False, verbose=False):
         subprocess.check_call(cmd)
     if force or _host_needs_build(CLI):
         os.makedirs(os.path.dirname(CLI), exist_ok=True)
-        cmd = [cxx] + common + ["-o", CLI] + srcs[:3] + ["-L" + PKG, "-lsgcount_hip", "-lz", "-Wl,-rpath,$ORIGIN/..",
+        cmd = [cxx] + common + ["-o", CLI] + srcs[:4] + ["-L" + PKG, "-lsgcount_hip", "-lz", "-Wl,-rpath,$ORIGIN/..",
                                                          "-Wl,-rpath," + PKG]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

@@ -375,8 +375,9 @@ static double unix_s() {
 }
 
 TextFeeder::TextFeeder(const std::string &path_, size_t slice_bytes, size_t ring, size_t threads, void *(*alloc)(size_t),
-                       void (*release)(void *), size_t inflate_threads)
+                       void (*release)(void *), size_t inflate_threads, size_t pgz_chunk)
     : path(path_), free_fn(release) {
+    pgz_chunk_bytes = pgz_chunk;
     fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) throw Error("No such file or directory (os error 2): " + path);
     unsigned char magic[2] = {0, 0};
@@ -417,9 +418,23 @@ TextFeeder::TextFeeder(const std::string &path_, size_t slice_bytes, size_t ring
             }
         }
     }
+    if (is_gz && !is_bgzf && std::max(threads, inflate_threads) > 1 && file_size >= 64 && S_ISREG(sb.st_mode)) {
+        // one deflate stream, several cores: chunks of the compressed file are decoded speculatively in parallel and stitched
+        // in order (run_pgz)
+        void *m = mmap(nullptr, file_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) { map = (const uint8_t *)m; is_pgz = true; madvise(m, file_size, MADV_SEQUENTIAL); }
+    }
     if (is_bgzf) {
         n_slices_known = (size_t)-1;                    // known when the member scan reaches the end of the file
         threads = std::max(threads, inflate_threads);   // inflating is several times the work of copying
+    } else if (is_pgz) {
+        n_slices_known = (size_t)-1;
+        threads = std::max(threads, inflate_threads);
+        slice_bytes = std::min<size_t>(slice_bytes, 32u << 20);
+        if (!pgz_chunk_bytes) pgz_chunk_bytes = std::min<size_t>(std::max<size_t>(file_size / (threads * 4), 1u << 20), 8u << 20);
+        pgz_chunks = (file_size + pgz_chunk_bytes - 1) / pgz_chunk_bytes;
+        pgz_pieces.resize(pgz_chunks);
+        pgz_window.assign(32768, 0);
     } else if (is_gz) {
         gz = gzdopen(dup(fd), "rb");
         if (!gz) { close(fd); throw Error("cannot open the gzip stream of " + path); }
@@ -449,6 +464,13 @@ TextFeeder::TextFeeder(const std::string &path_, size_t slice_bytes, size_t ring
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [this] { return (slots[0].ready && slots[0].index == 0) || failed; });
         if (!failed) first_byte = slots[0].len ? bufs[0][HEAD] : 0;
+    } else if (is_pgz) {
+        n_threads = std::min(n_threads, std::max<size_t>(pgz_chunks, 1));
+        for (size_t t = 0; t < n_threads; t++) workers.emplace_back([this] { run_pgz(); });
+        std::unique_lock<std::mutex> lk(mu);
+        size_t len0 = 0; bool eof0 = false;
+        cv.wait(lk, [&] { return failed || slice_ready_locked(0, len0, eof0); });
+        if (!failed) first_byte = len0 ? bufs[0][HEAD] : 0;
     } else if (is_gz) {
         // the first byte of the stream decides "FASTQ or not": inflate the first slice eagerly in the producer
         workers.emplace_back([this] { run_gz(); });
@@ -655,9 +677,191 @@ void TextFeeder::run_gz() {
     }
 }
 
+// parallel gzip: is slice k complete?  A slice is full (slice bytes) unless it is the stream's last one
+bool TextFeeder::slice_ready_locked(size_t k, size_t &len, bool &eof) const {
+    const Slot &sl = slots[k % ring_n];
+    const size_t have = sl.index == k ? sl.len : 0;
+    if (pgz_total_known) {
+        const size_t last = (size_t)(pgz_total / slice);
+        if (k > last) return false;
+        if (k == last) { len = (size_t)(pgz_total % slice); eof = true; return have == len; }
+    }
+    len = slice; eof = false;
+    return have == slice;
+}
+
+// One gzip stream, several threads (the decoder is sgh_inflate.cpp).  Every worker takes the next chunk of the COMPRESSED file,
+// looks for a deflate block start inside it and decodes from there to the first block boundary behind the chunk's end — before
+// anything in front of the chunk is known, so back-references into the preceding 32 KiB come out as markers.  The chunks are then
+// stitched in order (the "chain", one short critical section per chunk): a chunk whose start is where the chunk before ended is
+// accepted, its tail is resolved against the window handed over — which yields the window for the next chunk — and its body is
+// resolved into the pinned slices outside the lock; a chunk whose speculation failed (no start found, a false start, a block
+// that spans whole chunks) is decoded again from the true position with the window known: correct in every case, merely
+// sequential for that chunk.  CRC-32 / ISIZE of every member are checked over the resolved bytes (acquire).
+void TextFeeder::run_pgz() {
+    try {
+        for (;;) {
+            size_t k;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || failed || pgz_next >= pgz_chunks || pgz_next < pgz_chain + 2 * n_threads; });
+                if (stop || failed || pgz_next >= pgz_chunks) return;
+                k = pgz_next++;
+            }
+            const double t0 = now_s();
+            const size_t lo = k * pgz_chunk_bytes, hi = std::min(file_size, lo + pgz_chunk_bytes);
+            const size_t max_out = (size_t)1 << 31;
+            // the symbol buffer (2 bytes per byte of text) is kept from chunk to chunk: fresh pages for every chunk cost more than decoding
+            static thread_local std::vector<uint16_t> sym_keep;
+            InflateSpan span;
+            span.sym.swap(sym_keep);
+            span.sym.clear();
+            struct Keep { InflateSpan &s; std::vector<uint16_t> &k; ~Keep() { s.sym.clear(); s.sym.swap(k); } } keep{span, sym_keep};
+            auto reset_span = [&]() { span.sym.clear(); span.members.clear(); span.end_of_stream = false; span.start_bit = span.end_bit = 0; };
+            bool found = false;
+            uint64_t start = 0;
+            if (k == 0) {
+                // the first member's header, then its first block: nothing lies in front of it
+                size_t at = 10;
+                if (file_size < 18 || map[0] != 0x1f || map[1] != 0x8b || map[2] != 8) throw Error("not a gzip stream: " + path);
+                const unsigned flg = map[3];
+                if (flg & 4) at += 2 + (size_t)(map[at] + 256u * map[at + 1]);
+                if (flg & 8) { while (at < file_size && map[at]) at++; at++; }
+                if (flg & 16) { while (at < file_size && map[at]) at++; at++; }
+                if (flg & 2) at += 2;
+                if (at >= file_size) throw Error("corrupt gzip header in " + path);
+                start = 8ull * at; found = true;
+            } else {
+                found = find_block_start(map, file_size, 8ull * lo, 8ull * hi, start);
+            }
+            if (found && inflate_span(map, file_size, start, 8ull * hi, nullptr, span, max_out) != 0) { found = false; reset_span(); }
+            // ---- the chain: chunk k's true start, its window, its place in the output
+            uint8_t window[32768];
+            uint64_t out_off = 0;
+            bool empty = false;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || failed || pgz_chain == k; });
+                if (stop || failed) return;
+                if (k == 0) pgz_pos = start;
+                memcpy(window, pgz_window.data(), 32768);
+                const uint64_t pos = pgz_pos;
+                if (pgz_eos || (pos >= 8ull * hi && k + 1 < pgz_chunks)) {
+                    empty = true;                                  // the stream ended, or a block that began earlier covers this whole chunk
+                } else if (!(found && start == pos)) {
+                    lk.unlock();
+                    reset_span();
+                    const int rc = inflate_span(map, file_size, pos, 8ull * hi, k == 0 ? nullptr : window, span, max_out);
+                    if (rc != 0) throw Error(std::string(rc == -4 ? "trailing garbage behind the gzip stream in " : "corrupt gzip stream in ") + path);
+                    lk.lock();
+                    pgz_fallbacks++;
+                }
+                if (empty) reset_span();
+                else {
+                    // the window behind this chunk: the last 32 KiB of (window ++ resolved symbols)
+                    const size_t n = span.sym.size();
+                    uint8_t *nw = pgz_window.data();
+                    if (n >= 32768) {
+                        for (size_t i = 0; i < 32768; i++) { const uint16_t v = span.sym[n - 32768 + i]; nw[i] = v < 256 ? (uint8_t)v : window[v & 0x7FFFu]; }
+                    } else {
+                        memmove(nw, nw + n, 32768 - n);
+                        for (size_t i = 0; i < n; i++) { const uint16_t v = span.sym[i]; nw[32768 - n + i] = v < 256 ? (uint8_t)v : window[v & 0x7FFFu]; }
+                    }
+                    out_off = pgz_out;
+                    pgz_out += n;
+                    pgz_pos = span.end_bit;
+                    if (span.end_of_stream) { pgz_eos = true; pgz_total = pgz_out; pgz_total_known = true; }
+                }
+                if (k + 1 == pgz_chunks && !pgz_eos) throw Error("truncated gzip stream in " + path);
+                pgz_chain = k + 1;
+            }
+            cv.notify_all();
+            // ---- the body: symbols -> bytes, into the slices that hold [out_off, out_off + n)
+            const size_t n = span.sym.size();
+            // symbol -> byte: identity below 256, the window behind a marker
+            static thread_local std::vector<uint8_t> lut_keep;
+            if (lut_keep.size() != 65536) { lut_keep.assign(65536, 0); for (unsigned i = 0; i < 256; i++) lut_keep[i] = (uint8_t)i; }
+            uint8_t *const lut = lut_keep.data();
+            memcpy(lut + 0x8000, window, 32768);
+            std::vector<PgzPiece> pieces;
+            size_t done = 0, mi = 0;
+            uint32_t crc = (uint32_t)crc32(0L, Z_NULL, 0);
+            uint64_t piece_len = 0;
+            while (done < n || mi < span.members.size()) {
+                // member ends at the current position close a CRC piece
+                while (mi < span.members.size() && span.members[mi].at == done) {
+                    pieces.push_back(PgzPiece{crc, piece_len, true, span.members[mi].crc, span.members[mi].isize});
+                    crc = (uint32_t)crc32(0L, Z_NULL, 0); piece_len = 0; mi++;
+                }
+                if (done >= n) break;
+                const uint64_t g = out_off + done;
+                const size_t s_idx = (size_t)(g / slice), s_off = (size_t)(g % slice);
+                size_t m = std::min(n - done, slice - s_off);
+                if (mi < span.members.size()) m = std::min(m, span.members[mi].at - done);
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stop || failed || s_idx < released + ring_n; });
+                    if (stop || failed) return;
+                    Slot &sl = slots[s_idx % ring_n];
+                    if (sl.index != s_idx) { sl.index = s_idx; sl.ready = false; sl.pending = 0; sl.newlines = 0; sl.len = 0; sl.eof = false; }
+                }
+                uint8_t *dst = bufs[s_idx % ring_n] + HEAD + s_off;
+                const uint16_t *src = span.sym.data() + done;
+                for (size_t i = 0; i < m; i++) dst[i] = lut[src[i]];
+                crc = (uint32_t)crc32(crc, dst, (uInt)m);
+                piece_len += m;
+                const uint64_t nl = count_newlines(dst, m);
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    Slot &sl = slots[s_idx % ring_n];
+                    sl.len += m; sl.newlines += nl;
+                }
+                cv.notify_all();
+                done += m;
+            }
+            if (piece_len) pieces.push_back(PgzPiece{crc, piece_len, false, 0, 0});
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                pgz_pieces[k] = std::move(pieces);
+                pgz_bodies++;
+                busy_s += now_s() - t0;
+            }
+            cv.notify_all();
+        }
+    } catch (const std::exception &e) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!failed) { failed = true; error = e.what(); }
+        cv.notify_all();
+    }
+}
+
 bool TextFeeder::acquire(size_t k, uint8_t *&data, size_t &len, uint64_t &newlines, bool &eof) {
     const double t0 = now_s();
     std::unique_lock<std::mutex> lk(mu);
+    if (is_pgz) {
+        size_t l = 0; bool e = false;
+        // (the last slice also waits for every chunk to have filed its CRC pieces)
+        cv.wait(lk, [&] { return failed || (slice_ready_locked(k, l, e) && (!e || pgz_bodies == pgz_chunks)); });
+        wait_s += now_s() - t0;
+        if (failed) throw Error(error);
+        if (e && !pgz_verified) {
+            // every byte of the stream is in place: the CRC-32 and ISIZE of every gzip member, piece by piece
+            pgz_verified = true;
+            uint32_t crc = 0; uint64_t mlen = 0;
+            for (const auto &pcs : pgz_pieces)
+                for (const PgzPiece &pc : pcs) {
+                    crc = (uint32_t)crc32_combine(crc, pc.crc, (z_off_t)pc.len);
+                    mlen += pc.len;
+                    if (pc.member_end) {
+                        if (crc != pc.want_crc || (uint32_t)mlen != pc.want_isize) throw Error("corrupt gzip stream (CRC / length mismatch) in " + path);
+                        crc = 0; mlen = 0;
+                    }
+                }
+        }
+        const Slot &sl = slots[k % ring_n];
+        data = bufs[k % ring_n] + HEAD; len = l; newlines = (sl.index == k) ? sl.newlines : 0; eof = e;
+        return true;
+    }
     cv.wait(lk, [&] { return failed || (slots[k % ring_n].index == k && slots[k % ring_n].ready); });
     wait_s += now_s() - t0;
     if (failed) throw Error(error);
@@ -732,7 +936,7 @@ static bool count_fastq_text(sgc_sample *smp, const std::string &path, const Cou
         st->text_bytes = feed.is_gz ? 0 : feed.file_size;
         st->reader_threads = feed.n_threads;
         st->read_busy_s = feed.busy_s; st->read_wait_s = feed.wait_s; st->push_s = t_push; st->upload_wait_s = t_upwait;
-        st->gz = feed.is_gz; st->bgzf = feed.is_bgzf;
+        st->gz = feed.is_gz; st->bgzf = feed.is_bgzf; st->pgz = feed.is_pgz; st->pgz_fallbacks = feed.pgz_fallbacks;
         st->feeder_setup_s = t_feed1 - t_feed0; st->first_push_s = t_first_push < 0 ? 0 : t_first_push;
     }
     return true;
@@ -888,7 +1092,7 @@ void count(const CountOptions &opt_in) {
     const size_t hw = usable_cpus();
     if (opt.io_threads == 0) {
         opt.io_threads = std::max<size_t>(1, std::min<size_t>(8, hw / n_workers));
-        opt.inflate_threads = std::max<size_t>(1, std::min<size_t>(16, hw / n_workers));      // BGZF members, inflated in parallel
+        opt.inflate_threads = std::max<size_t>(1, std::min<size_t>(16, (hw > 1 ? hw - 1 : 1) / n_workers));      // gzip / BGZF, inflated in parallel
     }
     if (opt.scan_threads == 0) opt.scan_threads = std::max<size_t>(1, std::min<size_t>(16, (hw > 1 ? hw - 1 : 1) / n_workers));
     // Host scan (default for plain FASTQ text when the library has a packed record format: ACGT guides, L <= 30): the
@@ -1015,10 +1219,10 @@ void count(const CountOptions &opt_in) {
                 n_dev, n_ctx, n_threads, per_dev.c_str());
         for (size_t i = 0; i < n; i++) {
             const SampleStats &x = stats[i];
-            fprintf(f, "%s{\"device\": %d, \"reads\": %llu, \"text_bytes\": %llu, \"gz\": %s, \"bgzf\": %s, \"text_path\": %s, \"scan_path\": %s, \"host_copy_s\": %.6f, \"reader_threads\": %zu, "
+            fprintf(f, "%s{\"device\": %d, \"reads\": %llu, \"text_bytes\": %llu, \"gz\": %s, \"bgzf\": %s, \"parallel_gzip\": %s, \"gzip_chunks_decoded_in_order\": %zu, \"text_path\": %s, \"scan_path\": %s, \"host_copy_s\": %.6f, \"reader_threads\": %zu, "
                        "\"wall_s\": %.6f, \"read_busy_s\": %.6f, \"wait_for_text_s\": %.6f, \"push_s\": %.6f, \"wait_for_upload_s\": %.6f, "
                        "\"finish_s\": %.6f, \"feeder_setup_s\": %.6f, \"first_push_s\": %.6f, \"h2d_ms\": %.3f, \"ingest_kernels_ms\": %.3f, \"count_kernels_ms\": %.3f}",
-                    i ? ", " : "", sample_dev[i], (unsigned long long)x.reads, (unsigned long long)x.text_bytes, x.gz ? "true" : "false", x.bgzf ? "true" : "false",
+                    i ? ", " : "", sample_dev[i], (unsigned long long)x.reads, (unsigned long long)x.text_bytes, x.gz ? "true" : "false", x.bgzf ? "true" : "false", x.pgz ? "true" : "false", x.pgz_fallbacks,
                     x.text_path ? "true" : "false", x.scan_path ? "true" : "false", x.host_copy_s, x.reader_threads, x.wall_s, x.read_busy_s, x.read_wait_s, x.push_s,
                     x.upload_wait_s, x.finish_s, x.feeder_setup_s, x.first_push_s, x.h2d_ms, x.ingest_ms, x.count_ms);
         }

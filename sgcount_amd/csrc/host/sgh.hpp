@@ -118,7 +118,26 @@ struct SampleStats {                    // where one sample's wall time went (ho
     uint64_t text_bytes = 0, reads = 0;
     size_t reader_threads = 0;
     bool gz = false, bgzf = false, text_path = false;
+    bool pgz = false;                   // a plain gzip stream inflated by several threads (TextFeeder::run_pgz)
+    size_t pgz_fallbacks = 0;           // ... chunks of it that had to be decoded in order
 };
+
+// ---- deflate from the middle of a stream (sgh_inflate.cpp) -----------------------------------------------------------
+// What one speculative decode of a chunk of a gzip file yields: 16-bit symbols (< 256: a byte; 0x8000 | i: byte i of the unknown
+// 32 KiB in front of the chunk), the bit positions it covers, and the gzip members that ended inside it.
+struct InflateSpan {
+    std::vector<uint16_t> sym;
+    uint64_t start_bit = 0, end_bit = 0;
+    bool end_of_stream = false;
+    struct MemberEnd { size_t at; uint32_t crc, isize; };     // a member ends in front of symbol `at`; its trailer says crc / isize
+    std::vector<MemberEnd> members;
+};
+// first plausible (non-final, dynamic-Huffman, text-producing) block start in [from_bit, to_bit)
+bool find_block_start(const uint8_t *data, size_t size, uint64_t from_bit, uint64_t to_bit, uint64_t &found);
+// blocks from start_bit up to the first block boundary >= stop_bit (or the end of the stream); window: the 32 KiB in front of
+// start_bit if known (then no markers are produced), else null.  0 = ok, < 0 = not a valid deflate stream from there.
+int inflate_span(const uint8_t *data, size_t size, uint64_t start_bit, uint64_t stop_bit, const uint8_t *window, InflateSpan &out,
+                 size_t max_out);
 
 // Fills a small ring of (pinned) buffers with consecutive slices of a file's text and counts the newlines of every
 // slice on the way.  Plain files: `threads` readers pread() disjoint sub-ranges of a slice in parallel (page cache →
@@ -133,15 +152,17 @@ class TextFeeder {
     static constexpr size_t HEAD = 4u << 20;      // longest unfinished line that can be carried from one slice to the next
     // threads: readers of a plain file; inflate_threads (>= threads is used): inflaters of a BGZF file
     TextFeeder(const std::string &path, size_t slice_bytes, size_t ring, size_t threads, void *(*alloc)(size_t),
-               void (*release)(void *), size_t inflate_threads = 0);
+               void (*release)(void *), size_t inflate_threads = 0, size_t pgz_chunk = 0);
     ~TextFeeder();
     // blocks until slice k (k = 0, 1, 2, ... in order) is in its buffer; eof = this is the last slice
     bool acquire(size_t k, uint8_t *&data, size_t &len, uint64_t &newlines, bool &eof);
     uint8_t *buffer_of(size_t k) const { return bufs[k % ring_n]; }     // base of slice k's buffer (slice data at + HEAD)
     void release_below(size_t k);       // the buffers of slices < k may be refilled
     uint8_t first_byte = 0;             // first byte of the text
-    bool is_gz = false, is_bgzf = false;
+    bool is_gz = false, is_bgzf = false, is_pgz = false;      // is_pgz: one gzip stream inflated by several threads
     size_t file_size = 0, n_threads = 1;
+    size_t pgz_chunk_bytes = 0;          // compressed bytes per unit of speculative work (0 = chosen from the file size)
+    size_t pgz_fallbacks = 0;            // chunks whose speculative start was wrong or missing and that were decoded in order instead
     double busy_s = 0, wait_s = 0;      // Σ reader busy time; time the consumer waited for text
   private:
     struct Slot { size_t index = (size_t)-1, len = 0, pending = 0; uint64_t newlines = 0; bool ready = false, eof = false; };
@@ -149,11 +170,21 @@ class TextFeeder {
     void run_plain();
     void run_gz();
     void run_bgzf();
+    void run_pgz();                      // plain gzip, several threads: speculative decode of chunks (sgh_inflate.cpp), stitched in order
+    bool slice_ready_locked(size_t k, size_t &len, bool &eof) const;
     void plan_bgzf_slice(size_t k);      // under the lock: the members of slice k, from scan_off on
     void shutdown();
     const uint8_t *map = nullptr;        // BGZF: the compressed file, memory-mapped
     size_t scan_off = 0, planned = 0;    // BGZF: next member to plan; slices planned so far
     std::vector<std::vector<BlockRef>> plans;
+    // parallel gzip (run_pgz): the chain that stitches the chunks in order
+    struct PgzPiece { uint32_t crc; uint64_t len; bool member_end; uint32_t want_crc, want_isize; };
+    size_t pgz_chunks = 0, pgz_next = 0, pgz_chain = 0, pgz_bodies = 0;   // chunks in all; next to hand out; stitched so far; resolved and filed so far
+    uint64_t pgz_pos = 0, pgz_out = 0, pgz_total = 0;          // true bit position of the next chunk's first block; bytes produced so far; total (when known)
+    bool pgz_eos = false, pgz_total_known = false;
+    std::vector<uint8_t> pgz_window;                           // the 32 KiB in front of pgz_pos
+    std::vector<std::vector<PgzPiece>> pgz_pieces;             // per chunk, for the CRC check at the end
+    bool pgz_verified = false;
     std::string path;
     void (*free_fn)(void *);
     int fd = -1;

@@ -134,10 +134,11 @@ int sgh_fastx_stats(const char *path, uint64_t *n_records, uint64_t *seq_bytes, 
 // (cut at the last newline, carry the rest) and reports what it would push: parts, bytes, lines, and a checksum of
 // (first_line, bytes, newlines) per part folded with the bytes themselves
 int sgh_text_feeder_walk(const char *path, uint64_t slice_bytes, uint64_t threads, uint64_t *parts_out, uint64_t *bytes_out,
-                         uint64_t *lines_out, uint64_t *fnv_out, int *first_byte_out, int *is_gz_out) {
+                         uint64_t *lines_out, uint64_t *fnv_out, int *first_byte_out, int *is_gz_out, uint64_t pgz_chunk, uint64_t *fallbacks_out) {
     return guard([&] {
-        sgh::TextFeeder feed(path, (size_t)slice_bytes, 3, (size_t)threads, malloc, free);
-        *first_byte_out = feed.first_byte; *is_gz_out = (feed.is_gz ? 1 : 0) | (feed.is_bgzf ? 2 : 0);
+        sgh::TextFeeder feed(path, (size_t)slice_bytes, 3, (size_t)threads, malloc, free, 0, (size_t)pgz_chunk);
+        *first_byte_out = feed.first_byte; *is_gz_out = (feed.is_gz ? 1 : 0) | (feed.is_bgzf ? 2 : 0) | (feed.is_pgz ? 4 : 0);
+        struct Fin { sgh::TextFeeder &f; uint64_t *o; ~Fin() { if (o) *o = f.pgz_fallbacks; } } fin{feed, fallbacks_out};
         uint64_t parts = 0, bytes = 0, first_line = 0, h = 1469598103934665603ull;
         size_t carry = 0;
         for (size_t k = 0;; k++) {
@@ -186,6 +187,24 @@ int sgh_scan_records(const char *path, uint32_t L, int reverse, uint32_t offset,
             sc.release();
         }
         *n_out = total; *lines_out = sc.total_lines;
+    });
+}
+
+// throughput of the text path's byte source alone: every slice acquired and released, nothing looked at (tools/inflate_bench.py)
+int sgh_text_feeder_drain(const char *path, uint64_t slice_bytes, uint64_t threads, uint64_t pgz_chunk, uint64_t *bytes_out, uint64_t *lines_out,
+                          double *busy_s_out, uint64_t *fallbacks_out, int *kind_out) {
+    return guard([&] {
+        sgh::TextFeeder feed(path, (size_t)slice_bytes, 3, (size_t)threads, malloc, free, (size_t)threads, (size_t)pgz_chunk);
+        uint64_t bytes = 0, lines = 0;
+        for (size_t k = 0;; k++) {
+            uint8_t *data; size_t len; uint64_t nl; bool eof;
+            feed.acquire(k, data, len, nl, eof);
+            bytes += len; lines += nl;
+            feed.release_below(k + 1);
+            if (eof) break;
+        }
+        *bytes_out = bytes; *lines_out = lines; *busy_s_out = feed.busy_s; *fallbacks_out = feed.pgz_fallbacks;
+        *kind_out = (feed.is_gz ? 1 : 0) | (feed.is_bgzf ? 2 : 0) | (feed.is_pgz ? 4 : 0);
     });
 }
 

@@ -27,7 +27,7 @@ def load():
         L.sgh_last_error.restype = C.c_char_p
         for name in ("sgh_cli", "sgh_entropy_offset_group", "sgh_positional_entropy", "sgh_minimize_mse",
                      "sgh_generate_sample_names", "sgh_genemap_get", "sgh_genemap_missing", "sgh_generate_columns",
-                     "sgh_format_results", "sgh_library_info", "sgh_fastx_stats", "sgh_text_feeder_walk", "sgh_scan_records"):
+                     "sgh_format_results", "sgh_library_info", "sgh_fastx_stats", "sgh_text_feeder_walk", "sgh_scan_records", "sgh_text_feeder_drain"):
             getattr(L, name).restype = C.c_int
         _lib = L
     return _lib
@@ -117,15 +117,28 @@ def fastx_stats(path):
     return a.value, b.value, c.value
 
 
-def text_feeder_walk(path, slice_bytes=1 << 16, threads=3):
+def text_feeder_walk(path, slice_bytes=1 << 16, threads=3, pgz_chunk=0, info=None):
     """Walks a file through the text path's byte source (TextFeeder) exactly as count() does and returns
     (parts, bytes, lines, fnv1a-64 of all pushed bytes, first byte, is_gz) — is_gz is "bgzf" for a BGZF file (gzip members
-    inflated in parallel)."""
-    parts, nbytes, lines, fnv = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+    inflated in parallel).  pgz_chunk: compressed bytes per unit of work of the parallel decoder of plain gzip streams (0 = from
+    the file size); info (a dict) receives {"pgz": the stream went through that decoder, "fallbacks": chunks it decoded in order}."""
+    parts, nbytes, lines, fnv, fb_count = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_uint64()
     fb, gz = C.c_int(), C.c_int()
     _chk(load().sgh_text_feeder_walk(path.encode(), C.c_uint64(slice_bytes), C.c_uint64(threads), C.byref(parts), C.byref(nbytes),
-                                     C.byref(lines), C.byref(fnv), C.byref(fb), C.byref(gz)))
-    return parts.value, nbytes.value, lines.value, fnv.value, fb.value, ("bgzf" if gz.value & 2 else bool(gz.value))
+                                     C.byref(lines), C.byref(fnv), C.byref(fb), C.byref(gz), C.c_uint64(pgz_chunk), C.byref(fb_count)))
+    if info is not None:
+        info.update(pgz=bool(gz.value & 4), fallbacks=fb_count.value)
+    return parts.value, nbytes.value, lines.value, fnv.value, fb.value, ("bgzf" if gz.value & 2 else bool(gz.value & 1))
+
+
+def text_feeder_drain(path, slice_bytes=32 << 20, threads=8, pgz_chunk=0):
+    """Runs a file through the byte source of the text path and throws the bytes away: (bytes, newlines, Σ worker busy seconds,
+    chunks the parallel gzip decoder decoded in order, kind) — kind: "plain" | "gz" (one thread) | "pgz" (parallel gzip) | "bgzf"."""
+    nbytes, lines, fb, busy, kind = C.c_uint64(), C.c_uint64(), C.c_uint64(), C.c_double(), C.c_int()
+    _chk(load().sgh_text_feeder_drain(path.encode(), C.c_uint64(slice_bytes), C.c_uint64(threads), C.c_uint64(pgz_chunk), C.byref(nbytes),
+                                      C.byref(lines), C.byref(busy), C.byref(fb), C.byref(kind)))
+    k = kind.value
+    return nbytes.value, lines.value, busy.value, fb.value, ("bgzf" if k & 2 else "pgz" if k & 4 else "gz" if k & 1 else "plain")
 
 
 def scan_records(path, L, reverse=False, offset=0, recursion=True, threads=3, block_bytes=1 << 16, cap=None):

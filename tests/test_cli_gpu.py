@@ -216,6 +216,33 @@ def test_bgzf_input_is_inflated_in_parallel(cli, tmp_path, example_library_text,
     assert rc != 0 and ("BGZF" in err or "read error" in err)      # whichever reader meets the bad member first
 
 
+def test_plain_gzip_input_is_inflated_in_parallel(cli, tmp_path, example_library_text, example_reads):
+    """An ordinary .gz (one deflate stream, what `gzip` and the sequencers write and every example of the reference is) goes
+    through the multi-threaded speculative inflater of the text path (sgh_inflate.cpp): same table as the oracle on the plain
+    text, several gzip members included; --stats-json says so; a corrupt stream is an error."""
+    import json
+    text = example_reads["diff.sequence"] * 60
+    want = oracle_table(example_library_text, [text], ["diff"], [(False, 5)], False, True)
+    stats = os.path.join(str(tmp_path), "stats.json")
+    third = len(text) // 3
+    third -= third % 4          # (any byte position is fine: members are concatenated text)
+    for name, blob in (("one.fastq.gz", gzip.compress(text, 6)),
+                       ("three.fastq.gz", gzip.compress(text[:third], 1) + gzip.compress(text[third:2 * third], 9) + gzip.compress(text[2 * third:], 6))):
+        p = os.path.join(str(tmp_path), name)
+        open(p, "wb").write(blob)
+        rc, out, err = run(cli, "-l", LIB, "-i", p, "-a", "5", "-q", "-n", "diff", "--io-threads", "4", "--chunk-mb", "1", "--stats-json", stats)
+        assert rc == 0, err
+        assert out == want
+        s0 = json.load(open(stats))["samples"][0]
+        assert s0["text_path"] and s0["gz"] and s0["parallel_gzip"] and not s0["bgzf"] and s0["reads"] == 1101 * 60
+    blob = bytearray(gzip.compress(text, 6))
+    blob[len(blob) // 2] ^= 0x41
+    p = os.path.join(str(tmp_path), "bad.fastq.gz")
+    open(p, "wb").write(bytes(blob))
+    rc, out, err = run(cli, "-l", LIB, "-i", p, "-a", "5", "-q")
+    assert rc != 0 and ("gzip" in err or "read error" in err or "panicked" in err)
+
+
 def test_malformed_fastq_panics_like_the_reference(cli, tmp_path, example_reads):
     """fxread panics on a malformed record (unpinned): exit code 101, on the text path (GPU-verified marker
     bytes) and on the record-reader path alike; a truncated last record too."""

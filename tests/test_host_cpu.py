@@ -334,3 +334,58 @@ def test_bgzf_followed_by_plain_gzip_members_is_read_as_gzip(tmp_path):
         return h
     parts, nbytes, lines, h, first, flag = hostlib.text_feeder_walk(str(p), 1 << 16, 4)
     assert (nbytes, lines, h) == (len(body), body.count(b"\n"), fnv(body)) and first == ord("@") and flag is True
+
+
+def test_plain_gzip_streams_are_inflated_by_several_threads(tmp_path):
+    """A plain .gz (ONE deflate stream — what sequencers and `gzip` write, and what the reference inflates on the sample's single
+    thread, count.rs:24) is cut into chunks of compressed bytes that are decoded speculatively in parallel and stitched in order
+    (sgh_inflate.cpp + TextFeeder::run_pgz): every byte exactly once and in order, whatever the compression level, the chunk size
+    (smaller than a deflate block: blocks span chunks; larger than the file: one chunk), the slice size and the thread count;
+    several gzip members; a member boundary inside a chunk; data that is not text (every chunk then falls back to in-order
+    decoding); and a corrupt or truncated stream is an error, never a silent miscount."""
+    import gzip
+    import random
+    from sgcount_amd import hostlib
+    rng = random.Random(17)
+    recs = []
+    for i in range(12000):
+        n = rng.choice([36, 75, 100, 150, 151])
+        recs.append(b"@r%d extra words\n%s\n+\n%s\n" % (i, bytes(rng.choice(b"ACGTN") for _ in range(n)), bytes(rng.choice(b"FFFFF:,#I") for _ in range(n))))
+    text = b"".join(recs)
+
+    def fnv(b):
+        h = 1469598103934665603
+        for c in b:
+            h = ((h ^ c) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+
+    def check(blob, body, combos, expect_pgz=True):
+        p = tmp_path / "t.fastq.gz"
+        p.write_bytes(blob)
+        want = (len(body), body.count(b"\n") + (0 if body.endswith(b"\n") or not body else 1), fnv(body))
+        for slice_bytes, threads, chunk in combos:
+            info = {}
+            parts, nbytes, lines, h, first, flag = hostlib.text_feeder_walk(str(p), slice_bytes, threads, chunk, info)
+            assert (nbytes, lines, h) == want and flag is True and info["pgz"] == expect_pgz, (slice_bytes, threads, chunk, info)
+        return info
+    combos = ((1 << 16, 4, 0), (1 << 16, 3, 20_000), (100_000, 8, 65_536), (1 << 22, 2, 300_000), (1 << 18, 5, 7_000))
+    for level in (1, 6, 9):
+        check(gzip.compress(text, level), text, combos)
+    # several members (python's gzip, concatenated; zlib reads them as one stream), one of them tiny, one empty
+    third = len(text) // 3
+    multi = gzip.compress(text[:third], 6) + gzip.compress(b"", 6) + gzip.compress(text[third:third + 10], 1) + gzip.compress(text[third + 10:], 9)
+    check(multi, text, combos)
+    # no final newline
+    check(gzip.compress(text[:-1], 6), text[:-1], combos[:3])
+    # bytes that are not text: no speculative start is ever accepted, every chunk is decoded in order — still every byte, once
+    blob = bytes(rng.randrange(256) for _ in range(200_000)) + text[:300_000]
+    info = check(gzip.compress(b"@" + blob, 6), b"@" + blob, ((1 << 16, 4, 30_000),))
+    assert info["fallbacks"] >= 3
+    # a file too small for the parallel decoder goes through zlib
+    check(gzip.compress(b"@r\nAC\n+\nII\n", 6), b"@r\nAC\n+\nII\n", ((1 << 16, 4, 0),), expect_pgz=False)
+    # corrupt and truncated streams
+    good = gzip.compress(text, 6)
+    for bad in (good[: len(good) // 2], good[:-4], good[: len(good) // 3] + bytes([good[len(good) // 3] ^ 0x10]) + good[len(good) // 3 + 1:]):
+        (tmp_path / "bad.fastq.gz").write_bytes(bad)
+        with pytest.raises(hostlib.HostError):
+            hostlib.text_feeder_walk(str(tmp_path / "bad.fastq.gz"), 1 << 16, 4, 40_000)
