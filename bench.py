@@ -281,10 +281,12 @@ def e2e_block(wl, args, exact, cpu):
             "stages_first_run": stages_of(runs[0][1]),
         }
         # the validated fallback (and the path of .gz / BGZF input): the text itself goes over PCIe and the GPU parses it
-        wall_t, stats_t = _run_cli(cli, base + ["-i", fq, "--pack", "fastq"], stats=os.path.join(d, "stats_text.json"))
+        # (two runs, the better one: the first pread() of the file pays the LRU activation the scan path avoids — DESIGN.md §5)
+        text_runs = [_run_cli(cli, base + ["-i", fq, "--pack", "fastq"], stats=os.path.join(d, "stats_text.json")) for _ in range(2)]
+        wall_t, stats_t = min(text_runs, key=lambda r: r[0])
         smp_t = stats_t["samples"][0]
         out["plain_gpu_parsed_text"] = {
-            "wall_s": wall_t, "reads_per_s": n / wall_t, "table_equals_resident_pass": bool(np.array_equal(_table_counts(table, args.guides), want)),
+            "wall_s": wall_t, "wall_s_all_runs": [r[0] for r in text_runs], "reads_per_s": n / wall_t, "table_equals_resident_pass": bool(np.array_equal(_table_counts(table, args.guides), want)),
             "stages": stages_of(stats_t),
             "ingest_text_GBps_vs_hbm": {"achieved": size / max(smp_t["ingest_kernels_ms"], 1e-9) / 1e6, "peak": HBM_PEAK_GBPS,
                                          "note": "FASTQ text bytes / Σ(k_fastq_count + k_scan_tiles + k_fastq_pack) time"},

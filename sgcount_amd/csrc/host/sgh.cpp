@@ -19,6 +19,10 @@
 #include <thread>
 #include <unordered_set>
 
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
 #include "../../../include/sgcount_hip.h"
 
 namespace sgh {
@@ -617,7 +621,7 @@ void TextFeeder::run_bgzf() {
                 zs.next_in = (Bytef *)(map + r.in_off); zs.avail_in = r.in_len;
                 zs.next_out = dst + r.out_off; zs.avail_out = r.out_len;
                 const int rc = inflate(&zs, Z_FINISH);
-                if (rc != Z_STREAM_END || zs.avail_out != 0 || (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst + r.out_off, r.out_len) != r.crc)
+                if (rc != Z_STREAM_END || zs.avail_out != 0 || crc32_fast(0u, dst + r.out_off, r.out_len) != r.crc)
                     throw Error("corrupt BGZF member in " + path);
                 nl += count_newlines(dst + r.out_off, r.out_len);
             }
@@ -675,6 +679,96 @@ void TextFeeder::run_gz() {
         if (!failed) { failed = true; error = e.what(); }
         cv.notify_all();
     }
+}
+
+// CRC-32 of gzip (reflected polynomial 0xEDB88320), folded 64 bytes at a time with carry-less multiplies (the published
+// PCLMULQDQ method; the folding constants are x^k mod P for this polynomial); zlib's table-driven crc32() takes the bytes that are
+// left and stands in on other CPUs.  The member CRCs of the parallel gzip reader are computed with it over every resolved byte.
+#if defined(__x86_64__)
+__attribute__((target("pclmul,sse4.1"))) static uint32_t crc32_fold(const uint8_t *buf, size_t len /* multiple of 16, >= 64 */, uint32_t crc) {
+    alignas(16) static const uint64_t k1k2[2] = {0x0154442bd4ull, 0x01c6e41596ull};
+    alignas(16) static const uint64_t k3k4[2] = {0x01751997d0ull, 0x00ccaa009eull};
+    alignas(16) static const uint64_t k5k0[2] = {0x0163cd6124ull, 0x0000000000ull};
+    alignas(16) static const uint64_t poly[2] = {0x01db710641ull, 0x01f7011641ull};
+    __m128i x0, x1, x2, x3, x4, x5, x6, x7, x8, y5, y6, y7, y8;
+    x1 = _mm_loadu_si128((const __m128i *)(buf + 0x00)); x2 = _mm_loadu_si128((const __m128i *)(buf + 0x10));
+    x3 = _mm_loadu_si128((const __m128i *)(buf + 0x20)); x4 = _mm_loadu_si128((const __m128i *)(buf + 0x30));
+    x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)crc));
+    x0 = _mm_load_si128((const __m128i *)k1k2);
+    buf += 64; len -= 64;
+    while (len >= 64) {
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x6 = _mm_clmulepi64_si128(x2, x0, 0x00);
+        x7 = _mm_clmulepi64_si128(x3, x0, 0x00); x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+        x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x2 = _mm_clmulepi64_si128(x2, x0, 0x11);
+        x3 = _mm_clmulepi64_si128(x3, x0, 0x11); x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+        y5 = _mm_loadu_si128((const __m128i *)(buf + 0x00)); y6 = _mm_loadu_si128((const __m128i *)(buf + 0x10));
+        y7 = _mm_loadu_si128((const __m128i *)(buf + 0x20)); y8 = _mm_loadu_si128((const __m128i *)(buf + 0x30));
+        x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), y5); x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), y6);
+        x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), y7); x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), y8);
+        buf += 64; len -= 64;
+    }
+    x0 = _mm_load_si128((const __m128i *)k3k4);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
+    while (len >= 16) {
+        x2 = _mm_loadu_si128((const __m128i *)buf);
+        x5 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+        buf += 16; len -= 16;
+    }
+    x2 = _mm_clmulepi64_si128(x1, x0, 0x10);
+    x3 = _mm_setr_epi32(~0, 0, ~0, 0);
+    x1 = _mm_srli_si128(x1, 8);
+    x1 = _mm_xor_si128(x1, x2);
+    x0 = _mm_loadl_epi64((const __m128i *)k5k0);
+    x2 = _mm_srli_si128(x1, 4);
+    x1 = _mm_and_si128(x1, x3);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    x0 = _mm_load_si128((const __m128i *)poly);
+    x2 = _mm_and_si128(x1, x3);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x10);
+    x2 = _mm_and_si128(x2, x3);
+    x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
+    x1 = _mm_xor_si128(x1, x2);
+    return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+#endif
+uint32_t crc32_fast(uint32_t crc, const uint8_t *buf, size_t len) {
+#if defined(__x86_64__)
+    static const bool ok = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1");
+    if (ok && len >= 64) {
+        const size_t bulk = len & ~(size_t)15;
+        crc = ~crc32_fold(buf, bulk, ~crc);
+        buf += bulk; len -= bulk;
+    }
+#endif
+    while (len) { const uInt m = (uInt)std::min<size_t>(len, 1u << 30); crc = (uint32_t)crc32(crc, buf, m); buf += m; len -= m; }
+    return crc;
+}
+
+// symbols -> bytes: 32 symbols at a time when none of them is a marker (then it is a plain narrowing), through the table otherwise
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static void resolve_symbols_avx2(const uint16_t *src, size_t m, const uint8_t *lut, uint8_t *dst) {
+    size_t i = 0;
+    for (; i + 32 <= m; i += 32) {
+        const __m256i a = _mm256_loadu_si256((const __m256i *)(src + i)), b = _mm256_loadu_si256((const __m256i *)(src + i + 16));
+        if (_mm256_testz_si256(_mm256_or_si256(a, b), _mm256_set1_epi16((short)0xFF00))) {
+            const __m256i pk = _mm256_permute4x64_epi64(_mm256_packus_epi16(a, b), 0xD8);
+            _mm256_storeu_si256((__m256i *)(dst + i), pk);
+        } else {
+            for (size_t k = i; k < i + 32; k++) dst[k] = lut[src[k]];
+        }
+    }
+    for (; i < m; i++) dst[i] = lut[src[i]];
+}
+#endif
+static void resolve_symbols(const uint16_t *src, size_t m, const uint8_t *lut, uint8_t *dst) {
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (avx2) { resolve_symbols_avx2(src, m, lut, dst); return; }
+#endif
+    for (size_t i = 0; i < m; i++) dst[i] = lut[src[i]];
 }
 
 // parallel gzip: is slice k complete?  A slice is full (slice bytes) unless it is the stream's last one
@@ -807,8 +901,8 @@ void TextFeeder::run_pgz() {
                 }
                 uint8_t *dst = bufs[s_idx % ring_n] + HEAD + s_off;
                 const uint16_t *src = span.sym.data() + done;
-                for (size_t i = 0; i < m; i++) dst[i] = lut[src[i]];
-                crc = (uint32_t)crc32(crc, dst, (uInt)m);
+                resolve_symbols(src, m, lut, dst);
+                crc = crc32_fast(crc, dst, m);
                 piece_len += m;
                 const uint64_t nl = count_newlines(dst, m);
                 {

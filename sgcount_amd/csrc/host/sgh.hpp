@@ -108,6 +108,7 @@ void count(const CountOptions &opt);                     // count.rs:74-148
 
 // ---- FASTQ text at speed (the byte source of count()'s text path) ----------------------------------------
 size_t count_newlines(const uint8_t *p, size_t n);
+uint32_t crc32_fast(uint32_t crc, const uint8_t *buf, size_t len);     // zlib's crc32(), folded with carry-less multiplies where the CPU has them
 
 struct SampleStats {                    // where one sample's wall time went (host side; device side from sgc_timing)
     double wall_s = 0, read_busy_s = 0, read_wait_s = 0, push_s = 0, upload_wait_s = 0, finish_s = 0;

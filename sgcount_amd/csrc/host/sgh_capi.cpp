@@ -208,4 +208,6 @@ int sgh_text_feeder_drain(const char *path, uint64_t slice_bytes, uint64_t threa
     });
 }
 
+uint32_t sgh_crc32(uint32_t crc, const uint8_t *buf, uint64_t len) { return sgh::crc32_fast(crc, buf, (size_t)len); }
+
 }  // extern "C"

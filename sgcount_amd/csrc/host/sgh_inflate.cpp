@@ -254,7 +254,13 @@ static int inflate_block(Bits &b, std::vector<uint16_t> &out, size_t &n_io, cons
         if (dist <= n) {
             const uint16_t *src = dst - dist;
             if (dist >= len) memcpy(dst, src, 2 * (size_t)len);
-            else for (unsigned i = 0; i < len; i++) dst[i] = src[i];   // overlapping copies repeat, as deflate wants
+            else if (dist == 1) { const uint16_t v = src[0]; for (unsigned i = 0; i < len; i++) dst[i] = v; }      // a run of one symbol (quality strings)
+            else {
+                // an overlapping copy repeats the last `dist` symbols: lay one period down, then double what is there
+                memcpy(dst, src, 2 * dist);
+                size_t copied = dist;
+                while (copied < len) { const size_t c = std::min<size_t>(copied, len - copied); memcpy(dst + copied, dst, 2 * c); copied += c; }
+            }
         } else {
             for (unsigned i = 0; i < len; i++) {
                 const size_t at = n + i;                      // position being written

@@ -377,6 +377,12 @@ def test_plain_gzip_streams_are_inflated_by_several_threads(tmp_path):
     check(multi, text, combos)
     # no final newline
     check(gzip.compress(text[:-1], 6), text[:-1], combos[:3])
+    # very repetitive text (the bench's synthetic FASTQ: constant adapters, qualities all 'I' — long overlapping copies at
+    # distance 1 and markers that live long)
+    from sgcount_amd import synth
+    rep = synth.fastq_host(synth.library(500, 20), 0, 30000)
+    for level in (1, 9):
+        check(gzip.compress(rep, level), rep, ((1 << 16, 4, 9_000), (1 << 20, 6, 0), (1 << 18, 3, 50_000)))
     # bytes that are not text: no speculative start is ever accepted, every chunk is decoded in order — still every byte, once
     blob = bytes(rng.randrange(256) for _ in range(200_000)) + text[:300_000]
     info = check(gzip.compress(b"@" + blob, 6), b"@" + blob, ((1 << 16, 4, 30_000),))
@@ -389,3 +395,20 @@ def test_plain_gzip_streams_are_inflated_by_several_threads(tmp_path):
         (tmp_path / "bad.fastq.gz").write_bytes(bad)
         with pytest.raises(hostlib.HostError):
             hostlib.text_feeder_walk(str(tmp_path / "bad.fastq.gz"), 1 << 16, 4, 40_000)
+
+
+def test_folded_crc32_equals_zlib():
+    """crc32_fast (carry-less-multiply folding; every inflated byte of the gzip / BGZF readers goes through it) == zlib.crc32
+    for every length around the 16- and 64-byte boundaries of the folding and any starting value."""
+    import ctypes as C
+    import random
+    import zlib
+    from sgcount_amd import hostlib
+    L = hostlib.load()
+    L.sgh_crc32.restype = C.c_uint32
+    rng = random.Random(2)
+    for n in list(range(0, 200)) + [255, 256, 257, 1000, 4095, 4096, 65537, (1 << 20) + 3]:
+        b = bytes(rng.randrange(256) for _ in range(min(n, 300))) * (n // 300 + 1)
+        b = b[:n]
+        for init in (0, 0xDEADBEEF, 0xFFFFFFFF):
+            assert L.sgh_crc32(C.c_uint32(init), b, C.c_uint64(n)) == zlib.crc32(b, init), (n, init)

@@ -13,14 +13,23 @@ from sgcount_amd import hostlib          # noqa: E402
 
 
 def main():
-    reads = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
-    threads = [int(x) for x in sys.argv[2:]] or [1, 2, 4, 8]
+    synth_text = "--synth" in sys.argv          # the bench's synthetic FASTQ (constant adapters, qualities all 'I': ratio ~18)
+    argv = [a for a in sys.argv[1:] if a != "--synth"]
+    reads = int(argv[0]) if argv else 2_000_000
+    threads = [int(x) for x in argv[1:]] or [1, 2, 4, 8]
     d = "/dev/shm/sgc_inflate_%d" % os.getpid()
     os.makedirs(d, exist_ok=True)
     try:
         r = random.Random(5)
         fq = os.path.join(d, "r.fastq")
-        with open(fq, "wb") as f:
+        if synth_text:
+            from sgcount_amd import synth
+            lib = synth.library(100_000, 20)
+            with open(fq, "wb") as f:
+                for first in range(0, reads, 500_000):
+                    f.write(synth.fastq_host(lib, first, min(500_000, reads - first)))
+        else:
+          with open(fq, "wb") as f:
             bases = [bytes(r.choice(b"ACGT") for _ in range(150)) for _ in range(4096)]
             quals = [bytes(r.choice(b"FFFFFFFF:,#") for _ in range(150)) for _ in range(4096)]
             for i in range(reads):
