@@ -93,14 +93,19 @@ def _share_hip_runtime_with_torch():
         C.CDLL(cand, mode=C.RTLD_GLOBAL)
 
 
-def load():
-    """Loads (building first if needed) libsgcount_hip.so and binds every ABI symbol."""
+def load(so=None):
+    """Loads (building first if needed) libsgcount_hip.so and binds every ABI symbol.  so: another build of the same library to
+    load INSTEAD (the bounds-checked libsgcount_hip_check.so of tests/test_check_gpu.py) — only before the first load of a process."""
     global _lib
     if _lib is not None:
         return _lib
-    so = _build.SO
-    if _build.needs_build():
-        so = _build.build()
+    if so is not None:
+        if _build.needs_build(so):
+            _build.build_one(so)
+    else:
+        so = _build.SO
+        if _build.needs_build():
+            so = _build.build()
     if not os.path.exists(so):
         raise ImportError(f"{so} is missing: the HIP extension is required (no CPU fallback)")
     _share_hip_runtime_with_torch()

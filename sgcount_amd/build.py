@@ -16,6 +16,7 @@ CSRC = os.path.join(PKG, "csrc")
 INC = os.path.join(os.path.dirname(PKG), "include")
 SO = os.path.join(PKG, "libsgcount_hip.so")
 SYNTH_SO = os.path.join(PKG, "libsgcount_synth.so")
+CHECK_SO = os.path.join(PKG, "libsgcount_hip_check.so")     # the same sources with -DSGC_CHECK=1 (sgc_kernels.h): bounds-checked scratch indexing
 HOST_SO = os.path.join(PKG, "libsgcount_host.so")
 CLI = os.path.join(PKG, "bin", "sgcount-hip")
 HOST_SRCS = [os.path.join("host", f) for f in ("sgh.cpp", "sgh_scan.cpp", "sgh_inflate.cpp", "sgh_cli.cpp", "sgh_capi.cpp")]
@@ -40,6 +41,10 @@ def _deps(so):
     return [os.path.join(CSRC, f) for f in srcs + hdrs] + [os.path.abspath(__file__)]
 
 
+TARGETS[CHECK_SO] = TARGETS[SO]
+EXTRA_FLAGS = {CHECK_SO: ["-DSGC_CHECK=1"]}
+
+
 def needs_build(so=SO):
     if not os.path.exists(so):
         return True
@@ -52,7 +57,7 @@ def build_one(so, force=False, verbose=False):
         return so
     srcs, _ = TARGETS[so]
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-result", "-Wno-unused-value"] + os.environ.get("SGC_HIPCC_FLAGS", "").split() + \
+           "-Wno-unused-result", "-Wno-unused-value"] + EXTRA_FLAGS.get(so, []) + os.environ.get("SGC_HIPCC_FLAGS", "").split() + \
           ["-o", so] + [os.path.join(CSRC, f) for f in srcs]      # SGC_HIPCC_FLAGS: e.g. -DSGC_STAMPS=1 (tools/evidence.sh)
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

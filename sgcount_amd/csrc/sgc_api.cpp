@@ -327,7 +327,7 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
             const int six = !direct ? 0 :
                             (c->five_byte && 2u * (c->L + 2u) - slice_bits <= 40u && slice_bits + (uint32_t)sub <= 2u * c->v_lib.core_cl) ? 2 :
                             (c->six_byte && 2u * (c->L + 2u) + 2u <= 48u) ? 1 : 0;
-            { timed t(c, T_PART); sgc_launch_part_k1(c->stream, p, chunk, c->L, c->v_lib, tag_sub ? (uint32_t)sub : 0u, g, pool, desc, six); }
+            { timed t(c, T_PART); sgc_launch_part_k1(c->stream, s->d_err + 1, p, chunk, c->L, c->v_lib, tag_sub ? (uint32_t)sub : 0u, g, pool, desc, six); }
             if (core_path) {
                 // everything the slice probe does not settle (its misses + the generic partition) is resolved in LDS by the
                 // two core passes; k_count_slices itself lays those records out as pass A's runs
@@ -364,7 +364,7 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
                         cand &cd = cands.back();
                         for (int rep = 0; rep < 2; rep++) {
                             if (rep) ok = ok && hipEventRecord(e0, c->stream) == hipSuccess;
-                            sgc_launch_part_k1(c->stream, p, chunk, c->L, c->v_lib, (uint32_t)sub, g, (uint64_t *)cd.pool, desc, six);
+                            sgc_launch_part_k1(c->stream, s->d_err + 1, p, chunk, c->L, c->v_lib, (uint32_t)sub, g, (uint64_t *)cd.pool, desc, six);
                         }
                         ok = ok && hipEventRecord(e1, c->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
                              hipEventElapsedTime(&cd.ms, e0, e1) == hipSuccess;
@@ -391,7 +391,7 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
                     pool = (uint64_t *)c->d_pool;
                     HIP_TRY(hipGetLastError());
                     // the real pass starts over on the chosen pool
-                    { timed t(c, T_PART); sgc_launch_part_k1(c->stream, p, chunk, c->L, c->v_lib, tag_sub ? (uint32_t)sub : 0u, g, pool, desc, six); }
+                    { timed t(c, T_PART); sgc_launch_part_k1(c->stream, s->d_err + 1, p, chunk, c->L, c->v_lib, tag_sub ? (uint32_t)sub : 0u, g, pool, desc, six); }
                 }
                 uint64_t *buf0 = (uint64_t *)c->d_cbuf, *mrun = c->dense ? (uint64_t *)((char *)c->d_cbuf + cg.runs_a_bytes) : nullptr;
                 uint64_t *buf1 = (uint64_t *)((char *)c->d_cbuf + cg.runs_a_bytes + mrun_bytes);
@@ -485,7 +485,7 @@ static int count_bytes(sgc_sample *s, const uint8_t *d_text, const uint64_t *d_s
 extern "C" {
 
 const char *sgc_last_error(void) { return g_err.c_str(); }
-const char *sgc_version(void) { return "sgcount_hip 0.1.0 (gfx950)"; }
+const char *sgc_version(void) { return SGC_CHECK ? "sgcount_hip 0.1.0 (gfx950, bounds-checked build)" : "sgcount_hip 0.1.0 (gfx950)"; }
 
 uint32_t sgc_record_bytes(uint32_t L) {
     if (L == 0 || L > SGC_MAXL) return 0;
@@ -1269,11 +1269,14 @@ int sgc_sample_wait_uploads(sgc_sample *s, uint32_t max_pending) {
 
 // marker bytes / newline count reported by the ingest kernels (after a synchronisation of the stream)
 static int check_fastq_errors(sgc_sample *s) {
-    if (!s->fastq_pushed) return SGC_OK;
+    if (!s->fastq_pushed && !SGC_CHECK) return SGC_OK;
     sgc_ctx *c = s->ctx;
     unsigned long long e[2] = {0, 0};
     HIP_TRY(hipMemcpyAsync(e, s->d_err, 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (SGC_CHECK && (e[1] >> 8))
+        return fail(SGC_E_STATE, "internal bounds check failed in the partitioned pass (flags " + std::to_string(e[1] >> 8) +
+                                     ": 1 pool write, 2 block id, 4 block fill, 8 miss-run slot)");
     if (e[1] & 1ull) return fail(SGC_E_FORMAT, "FASTQ text: the newline count announced for a part differs from its contents");
     if (e[0]) return fail(SGC_E_FORMAT, "malformed FASTQ record: line " + std::to_string(~0ull - e[0]) +
                                            " does not start with its marker byte ('@' header / '+' separator)");

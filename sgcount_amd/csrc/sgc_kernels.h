@@ -7,6 +7,15 @@
 #define SGC_ABLATE 0
 #endif
 #define SGC_DBG(word, bits) (SGC_ABLATE && ((word) & (bits)))
+// -DSGC_CHECK=1 (a second library, libsgcount_hip_check.so, that tests/test_check_gpu.py runs the pass ladder on): every index the
+// partitioned pass computes into its scratch — pool blocks, slots inside a block, the miss runs — is compared with the bound of
+// that buffer; a violation sets a bit of the sample's error word and SKIPS the access instead of walking off the buffer (a fault
+// on this pool of GPUs takes the machine down), and sgc_sample_finish reports it as SGC_E_STATE.  In the shipped library
+// SGC_BOUND() is the constant true and costs nothing.
+#ifndef SGC_CHECK
+#define SGC_CHECK 0
+#endif
+#define SGC_BOUND(ok, errp, bit) (!SGC_CHECK || (ok) || (atomicOr((errp), 1ull << (bit)), false))
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -53,7 +62,7 @@ struct sgc_part_geometry {
 bool sgc_part_supported(const sgc_table_view &lib, bool rec16);
 void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_part_geometry *g);
 // sub_bits: with core-hashed slices, log2 (1..2) of core pass A's partitions per slice, tagged into the clean records; else 0
-void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib, uint32_t sub_bits,
+void sgc_launch_part_k1(hipStream_t st, unsigned long long *err /* the sample's error word (SGC_CHECK builds) */, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib, uint32_t sub_bits,
                         const sgc_part_geometry &g, uint64_t *pool, uint32_t *desc,
                         int slice_rec /* what the slice blocks hold: 0 = 8-byte records, 1 = six-byte (direct runs, core-hashed slices, 2 (L + 2) + 2 <= 48), 2 = five-byte (2 (L + 2) - slice bits <= 40) */);
 struct sgc_runs;       // sgc_runs.h

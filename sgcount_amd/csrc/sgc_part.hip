@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
                                                    uint32_t log2_slice, uint32_t core_cl, uint32_t sub_bits, uint64_t *__restrict__ pool,
                                                    uint32_t *__restrict__ desc, uint32_t *__restrict__ tail,
                                                    uint32_t tail_words, uint32_t *__restrict__ wcnt,
-                                                   uint32_t *__restrict__ wlist) {
+                                                   uint32_t *__restrict__ wlist, unsigned long long *__restrict__ err) {
     constexpr bool p6 = MODE == 2, p5 = MODE == 3;
     __shared__ uint64_t stage[PART_TILE];
     __shared__ uint8_t stage_p[PART_TILE];               // partition of every staged record
@@ -246,6 +246,7 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
             const uint4 rn = runs[p];
             const uint32_t at = j + (j - rn.x < rn.y ? rn.z : rn.w);       // record index in the pool (< 2^29: byte offsets fit 32 bits)
             char *pb = reinterpret_cast<char *>(pool);
+            if (!SGC_BOUND((at >> PART_LOG2_BLOCK) < gridDim.x * blocks_per_wg, err, 8)) continue;
             if ((p6 || p5) && p != P) {
                 const uint32_t bo = (at >> PART_LOG2_BLOCK) << (PART_LOG2_BLOCK + 3u), idx = (at + part_rot(at >> PART_LOG2_BLOCK)) & (PART_BLOCK - 1u);
                 *reinterpret_cast<uint32_t *>(pb + (size_t)(bo + (idx << 2))) = (uint32_t)r;
@@ -375,8 +376,11 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
         __syncthreads();                               // the previous round is done with list[]
         for (uint32_t i = t; i < nl; i += K2_THREADS) {
             const uint32_t o = win + i, w = find_extent<10>(pre, k1_wgs, o);
-            const uint32_t b = wlist[((size_t)w * PART_ARR + p) * blocks_per_wg + (o - pre[w])];
-            list[i] = (b << 11) | ((desc[b] & DESC_FILL_MASK) - 1u);
+            uint32_t b = wlist[((size_t)w * PART_ARR + p) * blocks_per_wg + (o - pre[w])];
+            unsigned long long *const err = reinterpret_cast<unsigned long long *>(matched) + 3;      // the sample's flag word behind `matched`
+            if (!SGC_BOUND(b < k1_wgs * blocks_per_wg && w < k1_wgs, err, 9)) b = 0;
+            const uint32_t fl = desc[b] & DESC_FILL_MASK;
+            list[i] = (b << 11) | ((SGC_BOUND(fl >= 1u && fl <= PART_BLOCK, err, 10) ? fl : 1u) - 1u);
         }
         __syncthreads();
         if (SGC_STAMPS && (dbg & 512)) { ts_scan += __builtin_amdgcn_s_memtime() - ts0; ts0 = __builtin_amdgcn_s_memtime(); n_groups_dbg += (nl + K2_U * (K2_THREADS / PART_BLOCK) - 1) / (K2_U * (K2_THREADS / PART_BLOCK)); }
@@ -465,7 +469,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 if (DIRECT) {
                     const uint32_t sub = (uint32_t)(cur[q] >> (P6 ? 2u * (L + 2u) : PART_SUB_SHIFT)) & 3u;
                     const uint32_t pos = atomicAdd(mv ? &wmiss4[sub] : &scratch[64u + (t & 63u)], 1u);
-                    if (mv) mrun[(uint64_t)run0 + sgc_mul24(sub, stretch) + pos] = cur[q] & (P6 ? (1ull << (2u * (L + 2u))) - 1ull : PART_TAG_MASK);
+                    if (mv && SGC_BOUND(pos < stretch, reinterpret_cast<unsigned long long *>(matched) + 3, 11)) mrun[(uint64_t)run0 + sgc_mul24(sub, stretch) + pos] = cur[q] & (P6 ? (1ull << (2u * (L + 2u))) - 1ull : PART_TAG_MASK);
                 } else if (DENSE) {
                     // (a ballot + one atomic by the lowest missing lane measured 0.02 ms slower than this predicated add)
                     const uint32_t pos = atomicAdd(mv ? &wmiss : &scratch[64u + (t & 63u)], 1u);
@@ -871,13 +875,13 @@ void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_
     g->block_records = PART_BLOCK;
 }
 
-void sgc_launch_part_k1(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib, uint32_t sub_bits,
+void sgc_launch_part_k1(hipStream_t st, unsigned long long *err, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib, uint32_t sub_bits,
                         const sgc_part_geometry &g, uint64_t *pool, uint32_t *desc, int slice_rec) {
     const bool core_hashed = lib.core_cl != 0 && lib.log2_slice < lib.log2_slots;
 #define K1_LAUNCH(MODE)                                                                                                            \
     hipLaunchKernelGGL((k_partition<MODE>), dim3(g.k1_wgs), dim3(K1_THREADS), 0, st, recs, n, g.per_wg, g.blocks_per_wg, L,          \
                        lib.log2_slots, lib.log2_slice, lib.core_cl, sub_bits, pool, desc, (uint32_t *)((char *)desc + g.desc_tail_off), \
-                       SGC_DESC_TAIL / 4, (uint32_t *)((char *)desc + g.wcnt_off), (uint32_t *)((char *)desc + g.wlist_off))
+                       SGC_DESC_TAIL / 4, (uint32_t *)((char *)desc + g.wcnt_off), (uint32_t *)((char *)desc + g.wlist_off), err)
     if (slice_rec == 2 && core_hashed) K1_LAUNCH(3);
     else if (slice_rec == 1 && core_hashed) K1_LAUNCH(2);
     else if (core_hashed) K1_LAUNCH(1);
