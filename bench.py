@@ -411,6 +411,33 @@ def e2e_block(wl, args, exact, cpu):
                            "note": "BGZF members are independent deflate streams: inflated in parallel straight into the pinned slices"}
             if cpu and "cpu_port_reads_per_s" in out.get("gz", {}):
                 out["bgzf"]["speedup_vs_cpu"] = out["bgzf"]["reads_per_s"] / out["gz"]["cpu_port_reads_per_s"]
+            # libraries with guides outside ACGT (upstream compares raw bytes: library.rs:89-99): the same text against the same
+            # library with an 'N' put into 100 of its guides (hybrid: packed pass + byte-string chain for the reads near those
+            # guides) and into 60 % of them (byte-string path alone), next to the all-ACGT library on the same GPU-parsed-text
+            # path.  Timing only: the tables differ from the ACGT library's by construction; parity is tests/test_generic_gpu.py.
+            seqs = wl.lib_seqs.copy()
+            libs = {}
+            for name, every in (("hybrid_100_N_guides", len(seqs) // 100), ("bytes_60pct_N_guides", 0)):
+                s2 = seqs.copy()
+                # (not among the last 200 guides: the planted Hamming-1 pairs there could become duplicates)
+                idx = np.arange(0, len(seqs) - 200, every) if every else np.arange(len(seqs) - 200)[np.arange(len(seqs) - 200) % 5 < 3]
+                s2[idx, 7] = ord("N")
+                lp = os.path.join(d, name + ".fa")
+                open(lp, "wb").write(synth.library_fasta(s2))
+                libs[name] = lp
+            libs["acgt"] = lib_path
+            legs = {}
+            for name, lp in libs.items():
+                b2 = ["-l", lp, "-a", "30", "-q", "-o", table] + (["-x"] if exact else [])
+                rr = [_run_cli(cli, b2 + ["-i", src, "--pack", "fastq"], stats=os.path.join(d, "stats_lib.json")) for _ in range(2)]
+                w, st2 = min(rr, key=lambda r: r[0])
+                s0 = st2["samples"][0]
+                legs[name] = {"wall_s": w, "reads_per_s": s0["reads"] / w, "sample_s": s0["wall_s"], "table_build_s": st2["table_build_s"],
+                              "count_kernels_s": s0["count_kernels_ms"] / 1e3, "ingest_kernels_s": s0["ingest_kernels_ms"] / 1e3}
+            out["non_acgt_libraries"] = dict(legs, reads=int(ngz),
+                                             hybrid_vs_acgt=legs["hybrid_100_N_guides"]["reads_per_s"] / legs["acgt"]["reads_per_s"],
+                                             bytes_vs_acgt=legs["bytes_60pct_N_guides"]["reads_per_s"] / legs["acgt"]["reads_per_s"],
+                                             note="FASTQ text parsed on the GPU (--pack fastq) in all three legs; best of two runs each")
     finally:
         shutil.rmtree(d, ignore_errors=True)
     return out

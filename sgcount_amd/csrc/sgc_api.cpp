@@ -92,6 +92,16 @@ struct sgc_ctx {
     sgc_core_view v_core[2] = {};
     // generic byte-string path (sgc_bytes.h): libraries the 2-bit records cannot represent
     bool bytes_mode = false;
+    // hybrid library (sgc_bytes.hip): the packed pass over the n_packed ACGT guides + the byte-string chain over all n guides for the
+    // reads a guide with other bytes could influence; d_gid_map: packed guide number -> library index; b_shadow: Bloom filter of the
+    // shadow keys (the ACGT windows one substitution away from a guide with exactly one byte outside ACGT)
+    bool hybrid = false, allow_hybrid = true;
+    uint32_t n_packed = 0;
+    uint32_t *d_gid_map = nullptr;
+    uint64_t *d_bloom_shadow = nullptr;
+    sgc_bloom_view b_shadow{};
+    void *d_flags = nullptr; size_t flags_cap = 0;      // per-read route flags of a hybrid push
+    void *d_lines = nullptr; size_t lines_cap = 0;      // ... and the (start, end) of the reads' sequence lines
     bool force_bytes = false;          // serve every library through the byte-string path (next sgc_set_library; tests)
     uint8_t *d_bytes_seqs = nullptr;
     uint64_t *d_bytes_tags[2] = {nullptr, nullptr};
@@ -148,6 +158,7 @@ struct sgc_sample {
     uint64_t since_fold = 0;     // reads counted into d_c32 since the last fold (u32 overflow guard)
     size_t state_bytes = 0;
     // sgc_sample_push_packed_async: two device batch buffers, filled by the upload stream, counted when full
+    uint32_t *d_c32p = nullptr;        // hybrid library: u32 counts of the packed pass, numbered over the ACGT guides
     void *d_acc[2] = {nullptr, nullptr};
     hipEvent_t ev_acc_use[2] = {nullptr, nullptr};   // the count pass that read d_acc[i] is done
     bool acc_used[2] = {false, false};
@@ -291,12 +302,21 @@ struct timed {
     }
 };
 
-static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
+// counts64 += counts32 (and, hybrid: the packed pass's counts through the guide map)
+static void fold_counts(sgc_sample *s) {
     sgc_ctx *c = s->ctx;
+    sgc_launch_fold(c->stream, s->d_c32, s->d_c64, c->n);
+    if (c->hybrid) sgc_launch_fold_map(c->stream, s->d_c32p, c->d_gid_map, s->d_c64, c->n_packed);
+    s->since_fold = 0;
+}
+
+static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n, bool add_total = true) {
+    sgc_ctx *c = s->ctx;
+    uint32_t *const c32 = c->hybrid ? s->d_c32p : s->d_c32;          // where the packed pass counts
+    const uint32_t n_g = c->hybrid ? c->n_packed : c->n;              // ... and how many guides it numbers
     // u32 device counters: fold into the u64 vector before any counter could wrap
     if (s->since_fold + n > 0xFFFFFFF0ull) {
-        sgc_launch_fold(c->stream, s->d_c32, s->d_c64, c->n);
-        s->since_fold = 0;
+        fold_counts(s);
     }
     uint64_t done = 0;
     while (done < n) {
@@ -399,26 +419,26 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
                 sgc_runs ra = sgc_core_runs_a(cg, c->v_core[0], c->L, buf0, zeroed, c->d_csmall);
                 if (tag_sub) ra.sub_bits = (uint32_t)sub;
                 uint32_t *mcur = (uint32_t *)zeroed + 2 * RUN_MAXP + 2;        // behind totals A | totals B | region cursors (zeroed by K1)
-                { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg, &ra,
+                { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, c32, s->d_matched, c->dbg, &ra,
                                                                  c->use_cuckoo ? c->d_lib_cuckoo : nullptr, mrun, mcur, direct, six); }
                 // timing: miss_ms = core pass A (+ its epilogue), hist_ms = core pass B
                 if (!c->one_mm) {
                     timed t(c, T_MISS, true);
                     sgc_launch_core(c->stream, 2, c->L, c->v_lib, c->v_perm, c->v_core[0], c->v_core[1], c->d_amb, cg, buf0, buf1, pool,
-                                    zeroed, c->d_csmall, s->d_c32, s->d_matched, c->dbg);
+                                    zeroed, c->d_csmall, c32, s->d_matched, c->dbg);
                 } else {
                 { timed t(c, T_MISS, true); sgc_launch_core(c->stream, 0, c->L, c->v_lib, c->v_perm, c->v_core[0], c->v_core[1], c->d_amb, cg, buf0, buf1, pool,
-                                                            zeroed, c->d_csmall, s->d_c32, s->d_matched, c->dbg); }
+                                                            zeroed, c->d_csmall, c32, s->d_matched, c->dbg); }
                 { timed t(c, T_HIST, true); sgc_launch_core(c->stream, 1, c->L, c->v_lib, c->v_perm, c->v_core[0], c->v_core[1], c->d_amb, cg, buf0, buf1, pool,
-                                                            zeroed, c->d_csmall, s->d_c32, s->d_matched, c->dbg); }
+                                                            zeroed, c->d_csmall, c32, s->d_matched, c->dbg); }
                 }
                 HIP_TRY(hipGetLastError());
                 done += chunk;
                 s->since_fold += chunk;
-                if (done < n) { sgc_launch_fold(c->stream, s->d_c32, s->d_c64, c->n); s->since_fold = 0; }
+                if (done < n) fold_counts(s);
                 continue;
             }
-            { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, s->d_c32, s->d_matched, c->dbg, nullptr, c->use_cuckoo ? c->d_lib_cuckoo : nullptr, nullptr, nullptr, false, 0); }
+            { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, c32, s->d_matched, c->dbg, nullptr, c->use_cuckoo ? c->d_lib_cuckoo : nullptr, nullptr, nullptr, false, 0); }
             rc = ensure(&c->d_gids, &c->gids_cap, g.gids_bytes);                // one slot per pool record: every read may miss
             if (rc) return rc;
             rc = ensure(&c->d_aux, &c->aux_cap, ((size_t)g.n_segs + 1) * 4);
@@ -427,16 +447,16 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
             // fork to the side stream here, join before the histogram
             HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
             HIP_TRY(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
-            sgc_launch_part_generic(c->side_stream, c->L, c->v_lib, c->v_perm, c->one_mm, g, pool, desc, s->d_c32, s->d_matched);
+            sgc_launch_part_generic(c->side_stream, c->L, c->v_lib, c->v_perm, c->one_mm, g, pool, desc, c32, s->d_matched);
             HIP_TRY(hipEventRecord(c->ev_join, c->side_stream));
             { timed t(c, T_MISS); sgc_launch_part_k3(c->stream, c->L, c->v_lib, c->v_perm, c->one_mm, c->b_lib, c->b_perm, g, pool, desc,
                                                      (uint32_t *)c->d_aux, (uint32_t *)c->d_gids, c->dbg); }
             HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-            { timed t(c, T_HIST); sgc_launch_part_k4(c->stream, c->n, g, (const uint32_t *)c->d_gids,
-                                                     (const uint32_t *)c->d_aux, s->d_c32, s->d_matched); }
+            { timed t(c, T_HIST); sgc_launch_part_k4(c->stream, n_g, g, (const uint32_t *)c->d_gids,
+                                                     (const uint32_t *)c->d_aux, c32, s->d_matched); }
         } else if (c->variant == 0) {
             timed t(c, T_LOOKUP);
-            sgc_launch_count_direct(c->stream, p, chunk, c->L, c->rec16, c->v_lib, c->v_perm, c->one_mm, s->d_c32,
+            sgc_launch_count_direct(c->stream, p, chunk, c->L, c->rec16, c->v_lib, c->v_perm, c->one_mm, c32,
                                     s->d_matched);
         } else {
             int rc = ensure(&c->d_gids, &c->gids_cap, (size_t)chunk * 4);
@@ -452,32 +472,46 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n) {
             }
             {
                 timed t(c, T_HIST);
-                sgc_launch_hist_slices(c->stream, (const uint32_t *)c->d_gids, chunk, c->n, s->d_c32);
+                sgc_launch_hist_slices(c->stream, (const uint32_t *)c->d_gids, chunk, n_g, c32);
             }
         }
         HIP_TRY(hipGetLastError());
         done += chunk;
         s->since_fold += chunk;
-        if (done < n) { sgc_launch_fold(c->stream, s->d_c32, s->d_c64, c->n); s->since_fold = 0; }
+        if (done < n) fold_counts(s);
     }
-    s->total += n;
+    if (add_total) s->total += n;
     return SGC_OK;
 }
 
 // the byte-string path (sgc_bytes.hip): read i = text[starts[i], ends[i])
-static int count_bytes(sgc_sample *s, const uint8_t *d_text, const uint64_t *d_starts, const uint64_t *d_ends, uint64_t n) {
+// flags (hybrid library): only the reads flagged for this chain take part, and the reads were already counted into the total
+static int count_bytes(sgc_sample *s, const uint8_t *d_text, const uint64_t *d_starts, const uint64_t *d_ends, uint64_t n, const uint8_t *flags = nullptr) {
     sgc_ctx *c = s->ctx;
     uint64_t done = 0;
     while (done < n) {
         const uint64_t chunk = std::min<uint64_t>(n - done, 1ull << 30);
-        if (s->since_fold + chunk > 0xFFFFFFF0ull) { sgc_launch_fold(c->stream, s->d_c32, s->d_c64, c->n); s->since_fold = 0; }
+        if (s->since_fold + chunk > 0xFFFFFFF0ull) fold_counts(s);
         { timed t(c, T_LOOKUP); sgc_launch_bytes_count(c->stream, c->v_bytes, d_text, d_starts + done, d_ends + done, chunk, s->reverse, s->offset,
-                                                       s->recursion, c->one_mm, s->d_c32, s->d_matched); }
+                                                       s->recursion, c->one_mm, s->d_c32, s->d_matched, flags ? flags + done : nullptr); }
         HIP_TRY(hipGetLastError());
         done += chunk; s->since_fold += chunk;
     }
-    s->total += n;
+    if (!flags) s->total += n;
     return SGC_OK;
+}
+
+// hybrid library: records + the reads' bytes -> route flags (flagged records die), the packed pass, the byte-string chain of the flagged
+static int count_hybrid(sgc_sample *s, uint64_t *d_recs, const uint8_t *d_text, const uint64_t *d_starts, const uint64_t *d_ends, uint64_t n) {
+    sgc_ctx *c = s->ctx;
+    int rc = ensure(&c->d_flags, &c->flags_cap, n ? n : 1);
+    if (rc) return rc;
+    { timed t(c, T_PACK); sgc_launch_bytes_route(c->stream, d_text, d_starts, d_ends, n, c->L, c->rec16, s->reverse, s->offset, s->recursion, d_recs,
+                                                 c->b_shadow, (uint8_t *)c->d_flags); }
+    HIP_TRY(hipGetLastError());
+    rc = count_records(s, d_recs, n);
+    if (rc) return rc;
+    return count_bytes(s, d_text, d_starts, d_ends, n, (const uint8_t *)c->d_flags);
 }
 
 // ---- ABI -------------------------------------------------------------------------------------------
@@ -531,7 +565,7 @@ int sgc_init(int device, sgc_ctx **out) {
 // every device allocation that belongs to the library tables of a ctx
 static std::vector<void *> table_ptrs(const sgc_ctx *c) {
     std::vector<void *> v = {c->d_lib_slots, c->d_lib_cuckoo, c->d_perm_slots, c->d_lib_vals, c->d_perm_vals, c->d_bloom_lib, c->d_bloom_perm,
-                             c->d_amb, c->d_core_filt, c->d_bytes_seqs, c->d_bytes_pl};
+                             c->d_amb, c->d_core_filt, c->d_bytes_seqs, c->d_bytes_pl, c->d_gid_map, c->d_bloom_shadow};
     for (int k = 0; k < 2; k++) {
         v.push_back(c->d_core_ents[k]); v.push_back(c->d_core_gids[k]); v.push_back(c->d_core_starts[k]);
         v.push_back(c->d_bytes_tags[k]); v.push_back(c->d_bytes_vals[k]);
@@ -556,6 +590,7 @@ static void free_tables(sgc_ctx *c) {
     c->b_lib = sgc_bloom_view{}; c->b_perm = sgc_bloom_view{};
     c->d_lib_slots = c->d_perm_slots = nullptr;
     c->d_lib_vals = c->d_perm_vals = nullptr;
+    c->d_gid_map = nullptr; c->d_bloom_shadow = nullptr; c->b_shadow = sgc_bloom_view{}; c->hybrid = false; c->n_packed = 0;
     c->has_lib = false;
 }
 
@@ -573,6 +608,7 @@ void sgc_free(sgc_ctx *c) {
     timing_drain(c);
     for (auto e : c->free_events) hipEventDestroy(e);
     free_tables(c);
+    dev_free(c->d_flags); dev_free(c->d_lines);
     dev_free(c->d_stage);
     dev_free(c->d_aux);
     dev_free(c->d_recs);
@@ -612,6 +648,7 @@ int sgc_ctx_clone(sgc_ctx *src, sgc_ctx **out) {
         c->v_core[k] = src->v_core[k];
         c->d_bytes_tags[k] = src->d_bytes_tags[k]; c->d_bytes_vals[k] = src->d_bytes_vals[k];
     }
+    c->hybrid = src->hybrid; c->n_packed = src->n_packed; c->d_gid_map = src->d_gid_map; c->d_bloom_shadow = src->d_bloom_shadow; c->b_shadow = src->b_shadow;
     c->bytes_mode = src->bytes_mode; c->d_bytes_seqs = src->d_bytes_seqs; c->d_bytes_pl = src->d_bytes_pl; c->v_bytes = src->v_bytes;
     // and the options that shape the passes
     c->variant = src->variant; c->per_lane = src->per_lane; c->k1_wgs = src->k1_wgs; c->max_chunk = src->max_chunk;
@@ -660,6 +697,7 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
     }
     if (!strcmp(key, "align_slices")) { c->align_slices = value != 0; return SGC_OK; }       // takes effect at the next sgc_set_library
     if (!strcmp(key, "force_bytes")) { c->force_bytes = value != 0; return SGC_OK; }         // takes effect at the next sgc_set_library
+    if (!strcmp(key, "hybrid")) { c->allow_hybrid = value != 0; return SGC_OK; }             // 0: a library with any byte outside ACGT is served by the byte-string path alone (next sgc_set_library)
     if (!strcmp(key, "dense")) { c->dense = value != 0; return SGC_OK; }
     if (!strcmp(key, "direct")) { c->direct = value != 0; return SGC_OK; }
     if (!strcmp(key, "six_byte")) { c->six_byte = value != 0; return SGC_OK; }
@@ -759,16 +797,12 @@ static int set_library_bytes(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32
                                 n, L, hb.lib_log2, hb.perm_log2};
     c->perm_entries = hb.perm_entries;
     c->bytes_mode = true;
-    c->n = n; c->L = L; c->one_mm = one_mm; c->rec16 = false; c->has_lib = true;
-    adopt_tables(c);
+    c->n = n; c->L = L; c->one_mm = one_mm; c->rec16 = false;
     return SGC_OK;
 }
 
-int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int enable_1mm) {
-    if (!c || !seqs) return fail(SGC_E_ARG, "sgc_set_library: NULL argument");
-    HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    free_tables(c);
+// the packed tables of an all-ACGT set of guides (every exit with an error leaves a half-built ctx for the caller's free_tables)
+static int set_library_packed(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int enable_1mm) {
     std::vector<uint64_t> keys;
     sgc_host_table h_lib, h_perm;
     std::string err;
@@ -780,10 +814,8 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
         fprintf(stderr, "sgc_set_library: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - lap_t).count());
         lap_t = now;
     };
-    if (c->force_bytes && L >= 1 && n >= 1) return set_library_bytes(c, seqs, n, L, enable_1mm != 0);
     const uint32_t want_cl = (c->align_slices && L >= 4 && L <= SGC_REC8_MAXL) ? (L - 2) / 2 : 0;
     int rc = sgc_build_library_table(seqs, n, L, SGC_LDS_LOG2_SLICE, want_cl, keys, h_lib, err);
-    if (rc == SGC_E_UNSUPPORTED && L >= 1 && n >= 1) return set_library_bytes(c, seqs, n, L, enable_1mm != 0);
     if (rc != SGC_OK) return fail(rc, "sgc_set_library: " + err);
     lap("library table (host)");
     rc = upload_table(h_lib, &c->d_lib_slots, &c->d_lib_vals, &c->v_lib, c->stream);
@@ -898,7 +930,75 @@ int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int
             }
         }
     }
-    c->n = n; c->L = L; c->one_mm = enable_1mm != 0; c->rec16 = L > SGC_REC8_MAXL; c->has_lib = true;
+    c->n = n; c->L = L; c->one_mm = enable_1mm != 0; c->rec16 = L > SGC_REC8_MAXL;
+    return SGC_OK;
+}
+
+int sgc_set_library(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, int enable_1mm) {
+    if (!c || !seqs) return fail(SGC_E_ARG, "sgc_set_library: NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    free_tables(c);
+    if (L == 0 || n == 0) return fail(n == 0 ? SGC_E_ARG : SGC_E_UNSUPPORTED, n == 0 ? "sgc_set_library: empty library" : "sgc_set_library: guide length 0");
+    // which guides can the packed records carry (ACGT only, at most SGC_MAXL bases)?
+    std::vector<uint32_t> acgt;                      // library indexes of the all-ACGT guides
+    if (L <= SGC_MAXL && !c->force_bytes) {
+        acgt.reserve(n);
+        for (uint32_t g = 0; g < n; g++) {
+            const uint8_t *q = seqs + (size_t)g * L;
+            bool ok = true;
+            for (uint32_t k = 0; k < L && ok; k++) ok = q[k] == 'A' || q[k] == 'C' || q[k] == 'G' || q[k] == 'T';
+            if (ok) acgt.push_back(g);
+        }
+    }
+    int rc;
+    if (acgt.size() == n) {
+        rc = set_library_packed(c, seqs, n, L, enable_1mm);
+    } else if (c->allow_hybrid && !acgt.empty() && (n - acgt.size()) * 2 <= (size_t)n) {
+        // hybrid (sgc_bytes.hip): byte-string tables over ALL guides, packed tables over the ACGT ones (numbered 0 .. n_packed - 1),
+        // the guide map, and the Bloom filter of the shadow keys
+        rc = set_library_bytes(c, seqs, n, L, enable_1mm != 0);
+        if (rc == SGC_OK) {
+            const uint64_t bytes_perm_entries = c->perm_entries;
+            std::vector<uint8_t> compact((size_t)acgt.size() * L);
+            for (size_t i = 0; i < acgt.size(); i++) memcpy(&compact[i * L], seqs + (size_t)acgt[i] * L, L);
+            rc = set_library_packed(c, compact.data(), (uint32_t)acgt.size(), L, enable_1mm);
+            if (rc == SGC_OK) {
+                std::vector<uint64_t> shadow;
+                std::vector<bool> is_acgt(n, false);
+                for (uint32_t g : acgt) is_acgt[g] = true;
+                for (uint32_t g = 0; g < n; g++) {
+                    if (is_acgt[g]) continue;
+                    const uint8_t *q = seqs + (size_t)g * L;
+                    uint32_t bad = 0, at = 0;
+                    for (uint32_t k = 0; k < L; k++) if (!(q[k] == 'A' || q[k] == 'C' || q[k] == 'G' || q[k] == 'T')) { bad++; at = k; }
+                    if (bad != 1) continue;              // two or more such bytes: no all-ACGT window is within one substitution
+                    uint64_t key = 0;
+                    for (uint32_t k = 0; k < L; k++) if (k != at) key |= (uint64_t)sgc_base_code(q[k]) << (2 * k);
+                    for (uint64_t b = 0; b < 4; b++) shadow.push_back(key | (b << (2 * at)));
+                }
+                uint32_t lw = 6;
+                while (lw < 20 && (1ull << lw) * 8 < shadow.size() * 2 + 64) lw++;       // >= 32 bits per key: almost no false positives
+                rc = upload_bloom(shadow, lw, &c->d_bloom_shadow, &c->b_shadow, c->stream);
+                if (rc == SGC_OK) {
+                    hipError_t e = hipMalloc((void **)&c->d_gid_map, acgt.size() * 4);
+                    if (e == hipSuccess) e = hipMemcpyAsync(c->d_gid_map, acgt.data(), acgt.size() * 4, hipMemcpyHostToDevice, c->stream);
+                    const hipError_t e2 = hipStreamSynchronize(c->stream);
+                    if (e == hipSuccess) e = e2;
+                    if (e != hipSuccess) rc = fail(e == hipErrorOutOfMemory ? SGC_E_OOM : SGC_E_HIP, std::string("sgc_set_library: ") + hipGetErrorString(e));
+                }
+                c->n_packed = (uint32_t)acgt.size();
+                c->n = n; c->hybrid = true; c->bytes_mode = false;
+                c->perm_entries = bytes_perm_entries;            // of the whole library, 'N' children included (src/permutes.rs map.len())
+            }
+        }
+    } else if (L <= SGC_BYTES_MAXL) {
+        rc = set_library_bytes(c, seqs, n, L, enable_1mm != 0);
+    } else {
+        rc = fail(SGC_E_UNSUPPORTED, "sgc_set_library: guides longer than 65535 bytes");
+    }
+    if (rc != SGC_OK) { const std::string keep = g_err; free_tables(c); g_err = keep; return rc; }
+    c->has_lib = true;
     adopt_tables(c);
     return SGC_OK;
 }
@@ -909,6 +1009,16 @@ int sgc_library_info(sgc_ctx *c, sgc_lib_info *out) {
     memset(out, 0, sizeof(*out));
     out->n_guides = c->n; out->guide_len = c->L; out->record_bytes = c->rec16 ? 16 : 8;
     out->one_mismatch = c->one_mm;
+    if (c->hybrid) {
+        // no packed records from outside (a host cannot know which reads need the byte-string chain): reads and FASTQ text only
+        out->record_bytes = 0; out->path = 2;
+        out->lib_slots = 1ull << c->v_bytes.lib_log2; out->perm_slots = c->one_mm ? 1ull << c->v_bytes.perm_log2 : 0;
+        out->perm_entries = c->perm_entries; out->core_partitions = c->has_core ? 1ull << c->v_core[0].log2_p : 0;
+        out->slices = sgc_part_supported(c->v_lib, c->rec16) ? 1u << (c->v_lib.log2_slots - c->v_lib.log2_slice) : 0;
+        out->table_bytes = (uint64_t)c->n * c->L + out->lib_slots * 12 + out->perm_slots * 16 + ((1ull << c->v_lib.log2_slots) * 16);
+        out->reserved_ = c->n_packed;          // guides the packed pass serves
+        return SGC_OK;
+    }
     if (c->bytes_mode) {
         out->record_bytes = 0;
         out->lib_slots = 1ull << c->v_bytes.lib_log2;
@@ -949,7 +1059,7 @@ int sgc_lookup(sgc_ctx *c, const uint8_t *tokens, uint64_t n, int which, int32_t
     if (which < 0 || which > 2) return fail(SGC_E_ARG, "sgc_lookup: which must be 0, 1 or 2");
     if (n == 0) return SGC_OK;
     HIP_TRY(hipSetDevice(c->device));
-    if (c->bytes_mode) {
+    if (c->bytes_mode || c->hybrid) {
         int rc = ensure(&c->d_stage, &c->stage_cap, n * c->L);
         if (rc) return rc;
         rc = ensure(&c->d_aux, &c->aux_cap, n * 4);
@@ -997,7 +1107,7 @@ int sgc_pack_reads_device(sgc_ctx *c, const uint8_t *d_seqs, const uint64_t *d_o
                           uint32_t offset, int position_recursion, void *d_records_out) {
     if (!c || !d_offsets || (!d_records_out && n)) return fail(SGC_E_ARG, "sgc_pack_reads_device: NULL argument");
     if (!c->has_lib) return fail(SGC_E_STATE, "sgc_pack_reads_device: no library set");
-    if (c->bytes_mode) return fail(SGC_E_STATE, "sgc_pack_reads_device: this library has no packed record format (sgc_library_info: record_bytes == 0)");
+    if (c->bytes_mode || c->hybrid) return fail(SGC_E_STATE, "sgc_pack_reads_device: this library has no packed record format (sgc_library_info: record_bytes == 0)");
     if (n == 0) return SGC_OK;
     HIP_TRY(hipSetDevice(c->device));
     {
@@ -1018,12 +1128,13 @@ int sgc_sample_begin(sgc_ctx *c, sgc_sample **out, int reverse, uint32_t offset,
     if (!s) return fail(SGC_E_OOM, "sgc_sample_begin: out of host memory");
     s->ctx = c; s->reverse = reverse != 0; s->offset = offset; s->recursion = position_recursion != 0;
     // one allocation: u64 counts[n] | u64 matched | u64 spare | u64 err[2] | u32 counts[n]  (one memset resets a sample)
-    s->state_bytes = (size_t)c->n * 8 + 32 + (size_t)c->n * 4;
+    s->state_bytes = (size_t)c->n * 8 + 32 + (size_t)c->n * 4 + (c->hybrid ? (size_t)c->n_packed * 4 : 0);
     hipError_t e = hipMalloc((void **)&s->d_c64, s->state_bytes);
     if (e != hipSuccess) { s->d_c64 = nullptr; sgc_sample_free(s); return fail(SGC_E_OOM, std::string("sgc_sample_begin: ") + hipGetErrorString(e)); }
     s->d_matched = s->d_c64 + c->n;
     s->d_err = s->d_c64 + c->n + 2;
     s->d_c32 = (uint32_t *)(s->d_c64 + c->n + 4);
+    s->d_c32p = c->hybrid ? s->d_c32 + c->n : nullptr;
     int rc = sgc_sample_reset(s);
     if (rc) { sgc_sample_free(s); return rc; }
     *out = s;
@@ -1054,7 +1165,7 @@ int sgc_sample_push_packed(sgc_sample *s, const void *records, uint64_t n, int w
     if (!s || (!records && n)) return fail(SGC_E_ARG, "sgc_sample_push_packed: NULL argument");
     if (n == 0) return SGC_OK;
     sgc_ctx *c = s->ctx;
-    if (c->bytes_mode)
+    if (c->bytes_mode || c->hybrid)
         return fail(SGC_E_STATE, "sgc_sample_push_packed: this library has no packed record format (sgc_library_info: record_bytes == 0); "
                                  "push reads or FASTQ text");
     HIP_TRY(hipSetDevice(c->device));
@@ -1090,7 +1201,7 @@ int sgc_sample_push_packed_async(sgc_sample *s, const void *records, uint64_t n)
     if (!s || (!records && n)) return fail(SGC_E_ARG, "sgc_sample_push_packed_async: NULL argument");
     if (n == 0) return SGC_OK;
     sgc_ctx *c = s->ctx;
-    if (c->bytes_mode)
+    if (c->bytes_mode || c->hybrid)
         return fail(SGC_E_STATE, "sgc_sample_push_packed_async: this library has no packed record format (sgc_library_info: record_bytes == 0)");
     HIP_TRY(hipSetDevice(c->device));
     const size_t rb = c->rec16 ? 16 : 8;
@@ -1153,6 +1264,7 @@ int sgc_sample_push_reads(sgc_sample *s, const uint8_t *seqs, const uint64_t *of
                                   c->d_recs);
     }
     HIP_TRY(hipGetLastError());
+    if (c->hybrid) return count_hybrid(s, c->d_recs, d_seqs, d_off, d_off + 1, n);
     return count_records(s, c->d_recs, n);
 }
 
@@ -1226,6 +1338,20 @@ static int push_fastq_part(sgc_sample *s, const uint8_t *text, uint64_t n_bytes,
                               s->reverse, s->offset, s->recursion, c->d_recs, s->d_err, (c->dbg >> 24) & 3u);
     }
     HIP_TRY(hipGetLastError());
+    if (c->hybrid) {
+        // the reads' bytes are needed too (route flags; the byte-string chain of the flagged): the (start, end) of every sequence line
+        rc = ensure(&c->d_lines, &c->lines_cap, (size_t)(n_records ? n_records : 1) * 16);
+        if (rc) return rc;
+        uint64_t *starts = (uint64_t *)c->d_lines, *ends = starts + n_records;
+        { timed t(c, T_PACK, true); sgc_launch_fastq_lines(c->stream, d_text, n_bytes, tile_scratch, first_line, (uint32_t)n_newlines, (uint32_t)lines,
+                                                           starts, ends, s->d_err); }
+        HIP_TRY(hipGetLastError());
+        s->fastq_pushed = true;
+        if (n_records_out) *n_records_out = n_records;
+        rc = count_hybrid(s, c->d_recs, d_text, starts, ends, n_records);
+        if (slot >= 0) { HIP_TRY(hipEventRecord(c->ev_use[slot], c->stream)); c->use_recorded[slot] = true; }      // the text is read to the end
+        return rc;
+    }
     if (slot >= 0) { HIP_TRY(hipEventRecord(c->ev_use[slot], c->stream)); c->use_recorded[slot] = true; }
     s->fastq_pushed = true;
     if (n_records_out) *n_records_out = n_records;
@@ -1296,9 +1422,8 @@ int sgc_sample_flush(sgc_sample *s) {
     sgc_ctx *c = s->ctx;
     HIP_TRY(hipSetDevice(c->device));
     { const int rc = flush_batch(s); if (rc) return rc; }
-    sgc_launch_fold(c->stream, s->d_c32, s->d_c64, c->n);
+    fold_counts(s);
     HIP_TRY(hipGetLastError());
-    s->since_fold = 0;
     return SGC_OK;
 }
 
@@ -1310,6 +1435,7 @@ int sgc_sample_export_device(sgc_sample *s, uint64_t *d_out) {
     HIP_TRY(hipSetDevice(c->device));
     { const int rc = flush_batch(s); if (rc) return rc; }
     // fold + export in one launch: d_out = counts64 (+= counts32) | total | matched
+    if (c->hybrid) sgc_launch_fold_map(c->stream, s->d_c32p, c->d_gid_map, s->d_c64, c->n_packed);
     sgc_launch_export(c->stream, s->d_c32, s->d_c64, s->d_matched, s->total, c->n, (unsigned long long *)d_out);
     HIP_TRY(hipGetLastError());
     s->since_fold = 0;

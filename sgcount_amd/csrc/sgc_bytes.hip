@@ -115,10 +115,11 @@ __device__ __forceinline__ uint32_t bytes_window(const sgc_bytes_view &v, const 
 
 __global__ void __launch_bounds__(256) k_bytes_count(const sgc_bytes_view v, const uint8_t *__restrict__ text, const uint64_t *__restrict__ starts,
                                                      const uint64_t *__restrict__ ends, uint64_t n_reads, int reverse, uint32_t o, int recursion,
-                                                     bool one_mm, uint32_t *__restrict__ counts, unsigned long long *__restrict__ matched) {
+                                                     bool one_mm, uint32_t *__restrict__ counts, unsigned long long *__restrict__ matched,
+                                                     const uint8_t *__restrict__ flags /* hybrid library: only the reads flagged for this chain (null = all) */) {
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     uint32_t g = SGC_NONE;
-    if (i < n_reads) {
+    if (i < n_reads && (!flags || flags[i])) {
         const uint64_t b = starts[i], e = ends[i];
         const uint8_t *s = text + b;
         const uint64_t len = e > b ? e - b : 0;
@@ -165,10 +166,73 @@ void sgc_launch_fastq_lines(hipStream_t st, const uint8_t *text, uint64_t n, con
 
 void sgc_launch_bytes_count(hipStream_t st, const sgc_bytes_view &v, const uint8_t *text, const uint64_t *starts, const uint64_t *ends,
                             uint64_t n_reads, int reverse, uint32_t o, int recursion, bool one_mm, uint32_t *counts,
-                            unsigned long long *matched) {
+                            unsigned long long *matched, const uint8_t *flags) {
     if (n_reads == 0) return;
     hipLaunchKernelGGL(k_bytes_count, dim3((unsigned)((n_reads + 255u) / 256u)), dim3(256), 0, st, v, text, starts, ends, n_reads, reverse, o,
-                       recursion, one_mm, counts, matched);
+                       recursion, one_mm, counts, matched, flags);
+}
+
+// ---- hybrid libraries: mostly ACGT guides, a few with other bytes ('N' above all) -------------------------------------------------
+// The packed pass is built over the ACGT guides alone; it is exact for every read that no other guide can influence.  A guide
+// g with a byte outside ACGT is within one substitution of a window W (src/counter.rs:111-117, src/permutes.rs:127-144) only if
+// W holds a byte outside ACGT itself, or g has exactly ONE such byte and W equals g everywhere else — one of four "shadow" keys
+// per such guide.  So a read goes to the byte-string chain over the WHOLE library (k_bytes_count, flagged) iff its span region
+// [o - 1, o + L + 1) holds a byte outside ACGT or one of its windows hits the Bloom filter of the shadow keys (a false positive
+// only costs the slower chain, which is always right); its packed record is replaced by the all-dead one.  Everything else
+// keeps its record: no guide outside ACGT is within distance one of any of its windows, so exact matches, unique parents and
+// ambiguity are decided among the ACGT guides exactly as in the whole library.
+template <bool REC16>
+__global__ void __launch_bounds__(256) k_bytes_route(const uint8_t *__restrict__ text, const uint64_t *__restrict__ starts, const uint64_t *__restrict__ ends,
+                                                     uint64_t n_reads, uint32_t L, int reverse, uint32_t o, int recursion, uint64_t *__restrict__ recs,
+                                                     sgc_bloom_view shadow, uint8_t *__restrict__ flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_reads) return;
+    const uint64_t b = starts[i], e = ends[i];
+    const uint8_t *s = text + b;
+    const uint64_t len = e > b ? e - b : 0;
+    const uint32_t n = (uint32_t)(len < 0xFFFFFFFFull ? len : 0xFFFFFFFFull), K = L + 2u;
+    bool route = false;
+    for (uint32_t w = 0; w < K && !route; w++) {
+        const int64_t p = (int64_t)o - 1 + (int64_t)w;
+        if (p < 0 || (uint64_t)p >= n) continue;
+        const uint8_t c = bytes_at(s, n, (uint32_t)p, reverse);
+        route = !(c == 'A' || c == 'C' || c == 'G' || c == 'T');
+    }
+    if (!route && shadow.words) {
+        const uint64_t span = REC16 ? recs[2 * i] : (recs[i] & ((1ull << (2u * K)) - 1ull)), kmask = sgc_key_mask(L);
+        const bool c_ok = (uint64_t)o + L <= n, p_ok = c_ok && recursion && (uint64_t)o + 1u + L <= n, m_ok = p_ok && o >= 1u;
+        const uint64_t keys[3] = {(span >> 2) & kmask, (span >> 4) & kmask, span & kmask};
+        const bool ok[3] = {c_ok, p_ok, m_ok};
+        for (int k = 0; k < 3 && !route; k++) {
+            if (!ok[k]) continue;
+            const uint64_t h2 = sgc_hash2(keys[k]);
+            const uint64_t m = sgc_bloom_mask(h2);
+            route = (shadow.words[sgc_bloom_word(h2, shadow.log2_words)] & m) == m;
+        }
+    }
+    flags[i] = route ? 1 : 0;
+    if (route) {
+        const uint64_t dead = (uint64_t)SGC_STATE_DEAD * (1u + K + K * K);
+        if (REC16) { recs[2 * i] = 0; recs[2 * i + 1] = dead; } else recs[i] = dead << (2u * K);
+    }
+}
+
+void sgc_launch_bytes_route(hipStream_t st, const uint8_t *text, const uint64_t *starts, const uint64_t *ends, uint64_t n_reads, uint32_t L, bool rec16,
+                            int reverse, uint32_t o, int recursion, uint64_t *recs, const sgc_bloom_view &shadow, uint8_t *flags) {
+    if (n_reads == 0) return;
+    const unsigned grid = (unsigned)((n_reads + 255u) / 256u);
+    if (rec16) hipLaunchKernelGGL((k_bytes_route<true>), dim3(grid), dim3(256), 0, st, text, starts, ends, n_reads, L, reverse, o, recursion, recs, shadow, flags);
+    else hipLaunchKernelGGL((k_bytes_route<false>), dim3(grid), dim3(256), 0, st, text, starts, ends, n_reads, L, reverse, o, recursion, recs, shadow, flags);
+}
+
+// counts64[map[i]] += packed counts32[i]; counts32[i] = 0  (the packed pass of a hybrid library numbers only its ACGT guides)
+__global__ void k_fold_map(uint32_t *__restrict__ c32p, const uint32_t *__restrict__ map, unsigned long long *__restrict__ c64, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const uint32_t v = c32p[i]; if (v) { c64[map[i]] += v; c32p[i] = 0; } }
+}
+void sgc_launch_fold_map(hipStream_t st, uint32_t *c32p, const uint32_t *map, unsigned long long *c64, uint32_t n) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_fold_map, dim3((n + 255) / 256), dim3(256), 0, st, c32p, map, c64, n);
 }
 
 void sgc_launch_bytes_lookup(hipStream_t st, const sgc_bytes_view &v, const uint8_t *tokens, uint64_t n, int which, bool one_mm, int32_t *out) {

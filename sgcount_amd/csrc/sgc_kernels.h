@@ -133,5 +133,10 @@ void sgc_launch_fastq_lines(hipStream_t st, const uint8_t *text, uint64_t n, con
                             uint32_t expect_nl, uint32_t n_lines, uint64_t *starts, uint64_t *ends, unsigned long long *err);
 void sgc_launch_bytes_count(hipStream_t st, const sgc_bytes_view &v, const uint8_t *text, const uint64_t *starts, const uint64_t *ends,
                             uint64_t n_reads, int reverse, uint32_t o, int recursion, bool one_mm, uint32_t *counts,
-                            unsigned long long *matched);
+                            unsigned long long *matched, const uint8_t *flags = nullptr);
+// hybrid libraries (sgc_bytes.hip): which reads need the byte-string chain over the whole library; their packed records are
+// replaced by dead ones; the packed pass's counts (numbered over the ACGT guides) are folded through the guide map
+void sgc_launch_bytes_route(hipStream_t st, const uint8_t *text, const uint64_t *starts, const uint64_t *ends, uint64_t n_reads, uint32_t L, bool rec16,
+                            int reverse, uint32_t o, int recursion, uint64_t *recs, const sgc_bloom_view &shadow, uint8_t *flags);
+void sgc_launch_fold_map(hipStream_t st, uint32_t *c32p, const uint32_t *map, unsigned long long *c64, uint32_t n);
 void sgc_launch_bytes_lookup(hipStream_t st, const sgc_bytes_view &v, const uint8_t *tokens, uint64_t n, int which, bool one_mm, int32_t *out);

@@ -219,3 +219,122 @@ def test_fastq_parts_on_the_byte_path(S, reverse):
     bad[text.index(b"@r77\n")] = ord("#")
     _count_parts(torch, S, dl, _cut_at_lines(bytes(bad), rng, 3), reverse, o, True, ffi.MEM_HOST, finish_rc=ffi.E_FORMAT)
     assert b"does not start with its marker byte" in dl.lib.sgc_last_error()
+
+
+def _hybrid_library(rng, L, n_guides, frac_other):
+    """mostly ACGT guides, a fraction with bytes outside ACGT (one 'N' mostly; two; a lowercase letter), and planted neighbours:
+    ACGT guides that equal an 'N' guide up to that position (the shadow keys), pairs at distance 1 and 2 across both kinds"""
+    guides, seen = [], set()
+
+    def add(s):
+        s = bytes(s)
+        if s not in seen:
+            seen.add(s); guides.append(s)
+    while len(guides) < n_guides:
+        u = rng.random()
+        if guides and u < 0.25:
+            s = bytearray(rng.choice(guides))                         # a neighbour of an existing guide (either kind)
+            for _ in range(rng.choice([1, 1, 2])):
+                s[rng.randrange(L)] = rng.choice(b"ACGT")
+            add(s)
+        elif u < 0.25 + frac_other:
+            s = bytearray(rng.choice(b"ACGT") for _ in range(L))
+            kind = rng.random()
+            if kind < 0.7:
+                s[rng.randrange(L)] = ord("N")
+            elif kind < 0.85:
+                s[rng.randrange(L)] = ord("N"); s[rng.randrange(L)] = ord("N")
+            else:
+                s[rng.randrange(L)] = rng.choice(b"acgtRY")
+            add(s)
+        else:
+            add(bytearray(rng.choice(b"ACGT") for _ in range(L)))
+    return guides
+
+
+@pytest.mark.parametrize("L,n_guides,frac", [(20, 2000, 0.01), (20, 1500, 0.10), (12, 600, 0.30), (24, 800, 0.05), (6, 60, 0.2)])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_hybrid_library_vs_oracle(S, L, n_guides, frac, reverse):
+    """A library with a FEW guides outside ACGT ('N', lowercase): the packed pass serves the ACGT guides and only the reads a
+    guide of the other kind could influence — a byte outside ACGT in the span region, or a window one substitution away from a
+    single-'N' guide — take the byte-string chain over the whole library (sgc_bytes.hip, k_bytes_route).  Same table as the
+    oracle (which compares bytes, like upstream: library.rs:89-99, permutes.rs:3,127-144) for reads and FASTQ text, both strands,
+    with and without the single-mismatch level and the position recursion; and the same as the byte-string path alone."""
+    rng = random.Random(1000 * L + n_guides + reverse)
+    o = 6
+    guides = _hybrid_library(rng, L, n_guides, frac)
+    n_other = sum(1 for g in guides if any(c not in b"ACGT" for c in g))
+    assert 0 < n_other * 2 <= len(guides)
+    reads = []
+    for _ in range(15000):
+        g = bytearray(rng.choice(guides))
+        u = rng.random()
+        if u < 0.35:
+            g[rng.randrange(L)] = rng.choice(b"ACGTNacgtRJ")
+        elif u < 0.45:
+            g[rng.randrange(L)] = rng.choice(b"ACGTN"); g[rng.randrange(L)] = rng.choice(b"ACGTN")
+        elif u < 0.5:
+            g = bytearray(rng.choice(b"ACGTN") for _ in range(L))
+        pre = bytes(rng.choice(b"ACGTN") if rng.random() < 0.02 else rng.choice(b"ACGT") for _ in range(max(o + rng.choice([0, 0, 0, 1, -1, 2]), 0)))
+        tail = bytes(rng.choice(b"ACGT") for _ in range(rng.choice([0, 1, 2, 5, 30])))
+        r = pre + bytes(g) + tail
+        if rng.random() < 0.03:
+            r = r[: rng.randrange(len(r) + 1)]
+        reads.append(r)
+    if reverse:
+        reads = [bytes((c ^ 4) if (c & 2) else (c ^ 21) for c in reversed(r)) if rng.random() < 0.97 else r for r in reads]
+    lib_text, reads_text = _fasta(guides), _reads_fasta(reads)
+    lib = _lib(S, lib_text)
+    perm = S.Permuter.new(lib.keys())
+    info = lib.device(True).info()
+    assert info.path == 2 and info.record_bytes == 0 and info.reserved_ == len(guides) - n_other
+    off = S.Offset.Reverse(o) if reverse else S.Offset.Forward(o)
+    for exact in (False, True):
+        for recursion in (True, False):
+            want, tot, mat = O.count_text(lib_text, reads_text, reverse, o, exact, recursion)
+            for pack in ("device", "fastq"):
+                rs = [r for r in S.parse_fastx(reads_text)]
+                ctr = S.Counter.new(iter(rs), lib, None if exact else perm, off, L, recursion, pack=pack, batch=4001)
+                assert ctr.guide_counts().tolist() == want, (exact, recursion, pack)
+                assert (ctr.total_reads(), ctr.matched_reads()) == (tot, mat)
+    # lookups go through the whole library's byte-string tables
+    dl = lib.device(True)
+    toks = [bytes(g) for g in guides[:50]]
+    assert dl.lookup(toks, which=0).tolist() == list(range(50))
+    # the byte-string path alone ("hybrid" off) gives the same table
+    both = []
+    for opts in ({}, {"hybrid": 0}):
+        ctr = S.Counter.new(S.parse_fastx(reads_text), lib, perm, off, L, True, pack="device", options=opts)
+        both.append(ctr.guide_counts().tolist())
+    assert both[0] == both[1]
+
+
+def test_hybrid_cli_table(tmp_path):
+    """the command line with a library of 3000 guides, 30 of them with an 'N': the oracle's table from plain and gzipped FASTQ"""
+    import gzip
+    import subprocess
+    from sgcount_amd import hostlib
+    rng = random.Random(8)
+    guides = _hybrid_library(rng, 20, 3000, 0.01)
+    lib_text = _fasta(guides, b"sg")
+    reads = []
+    for i in range(30000):
+        g = bytearray(rng.choice(guides))
+        if rng.random() < 0.3:
+            g[rng.randrange(20)] = rng.choice(b"ACGTN")
+        reads.append(bytes(rng.choice(b"ACGT") for _ in range(9 + rng.choice([0, 0, 1, -1]))) + bytes(g) + b"GATTACAGATTACA")
+    text = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)) for i, r in enumerate(reads))
+    lp, fq = str(tmp_path / "lib.fa"), str(tmp_path / "r.fastq")
+    open(lp, "wb").write(lib_text)
+    open(fq, "wb").write(text)
+    open(fq + ".gz", "wb").write(gzip.compress(text, 6))
+    lib = O.Library(lib_text)
+    ctr = O.Counter(lib, O.Permuter(lib), False, 9, 20, True).feed_text(text)
+    seen, row = set(), []
+    for ident in lib.ids():
+        row.append(0 if ident in seen else ctr.get_value(ident)); seen.add(ident)
+    want = O.format_results(lib, [row], ["r"], None, False)
+    for path in (fq, fq + ".gz"):
+        p = subprocess.run([hostlib.cli_path(), "-l", lp, "-i", path, "-a", "9", "-q", "-n", "r"], capture_output=True, timeout=300)
+        assert p.returncode == 0, p.stderr.decode()
+        assert p.stdout.decode() == want
