@@ -4,6 +4,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
+#include <thread>
 #include <utility>
 
 #include "../../include/sgcount_hip.h"
@@ -338,18 +340,32 @@ int sgc_build_bytes_tables(const uint8_t *seqs, uint32_t n, uint32_t L, bool one
     }
     out.perm_entries = 0;
     if (!one_mm) return SGC_OK;
-    // children: every guide, every position, every letter of the lexicon that differs (src/permutes.rs:3,78-117)
+    // children: every guide, every position, every letter of the lexicon that differs (src/permutes.rs:3,78-117).  8.0 M of them for
+    // 100k guides of 20 bases: generated, sorted by hash and screened by a few threads — buckets by the top bits of the hash, so that a
+    // run of equal hashes never straddles two buckets (a second was the whole of the CLI's start-up with such a library).
     static const uint8_t LEX[5] = {'A', 'C', 'G', 'T', 'N'};
     struct Kid { uint64_t h; uint32_t g, j; uint8_t b; };
-    std::vector<Kid> kids;
-    kids.reserve((size_t)n * L * 4);
-    for (uint32_t g = 0; g < n; g++) {
-        const uint8_t *w = seqs + (size_t)g * L;
-        for (uint32_t j = 0; j < L; j++)
-            for (uint8_t b : LEX)
-                if (b != w[j]) kids.push_back(Kid{bytes_hash_sub(w, L, j, b), g, j, b});
-    }
-    std::sort(kids.begin(), kids.end(), [](const Kid &a, const Kid &b) { return a.h < b.h; });
+    const unsigned T = std::max(1u, std::min(8u, std::min(std::thread::hardware_concurrency(), n / 2048u + 1u)));
+    constexpr unsigned NB = 64;                                              // buckets: the top 6 bits of the hash
+    std::vector<std::vector<std::vector<Kid>>> gen(T, std::vector<std::vector<Kid>>(NB));
+    auto generate = [&](unsigned t) {
+        const uint32_t g0 = (uint32_t)((uint64_t)n * t / T), g1 = (uint32_t)((uint64_t)n * (t + 1) / T);
+        for (auto &v : gen[t]) v.reserve((size_t)(g1 - g0) * L * 4 / NB + 16);
+        std::vector<uint64_t> prefix(L + 1);
+        for (uint32_t g = g0; g < g1; g++) {
+            const uint8_t *w = seqs + (size_t)g * L;
+            prefix[0] = sgc_bytes_hash_init();
+            for (uint32_t i = 0; i < L; i++) prefix[i + 1] = sgc_bytes_hash_step(prefix[i], w[i]);      // the hash state in front of every position
+            for (uint32_t j = 0; j < L; j++)
+                for (uint8_t bb : LEX) {
+                    if (bb == w[j]) continue;
+                    uint64_t h = sgc_bytes_hash_step(prefix[j], bb);
+                    for (uint32_t i = j + 1; i < L; i++) h = sgc_bytes_hash_step(h, w[i]);
+                    h = sgc_bytes_hash_fin(h);
+                    gen[t][h >> 58].push_back(Kid{h, g, j, bb});
+                }
+        }
+    };
     auto same_child = [&](const Kid &a, const Kid &b) {                       // do two (guide, position, letter) triples spell one string?
         const uint8_t *x = seqs + (size_t)a.g * L, *y = seqs + (size_t)b.g * L;
         for (uint32_t i = 0; i < L; i++) {
@@ -358,24 +374,52 @@ int sgc_build_bytes_tables(const uint8_t *seqs, uint32_t n, uint32_t L, bool one
         }
         return true;
     };
-    std::vector<size_t> keep;
-    std::vector<uint8_t> child(L);
-    for (size_t i = 0; i < kids.size();) {
-        size_t e = i;
-        while (e < kids.size() && kids[e].h == kids[i].h) e++;
-        // inside a run of equal hashes (almost always one string): a child survives iff no other triple spells the same string
-        for (size_t a = i; a < e; a++) {
-            bool unique = true;
-            for (size_t b = i; b < e && unique; b++)
-                if (b != a && same_child(kids[a], kids[b])) unique = false;
-            if (!unique) continue;
-            const uint8_t *w = seqs + (size_t)kids[a].g * L;
-            for (uint32_t k = 0; k < L; k++) child[k] = k == kids[a].j ? kids[a].b : w[k];
-            if (lib_find(kids[a].h, child.data()) != SGC_NONE) continue;       // a library member is a parent: nulled (permutes.rs:149-152)
-            keep.push_back(a);
+    std::vector<std::vector<Kid>> kept(NB);
+    auto screen = [&](unsigned t) {
+        std::vector<uint8_t> child(L);
+        for (unsigned bk = t; bk < NB; bk += T) {
+            std::vector<Kid> kids;
+            size_t total = 0;
+            for (unsigned u = 0; u < T; u++) total += gen[u][bk].size();
+            kids.reserve(total);
+            for (unsigned u = 0; u < T; u++) { kids.insert(kids.end(), gen[u][bk].begin(), gen[u][bk].end()); std::vector<Kid>().swap(gen[u][bk]); }
+            // (guide, position, letter) breaks ties, so that the result does not depend on the number of threads
+            std::sort(kids.begin(), kids.end(), [](const Kid &a, const Kid &b) { return a.h != b.h ? a.h < b.h : (a.g != b.g ? a.g < b.g : (a.j != b.j ? a.j < b.j : a.b < b.b)); });
+            for (size_t i = 0; i < kids.size();) {
+                size_t e = i;
+                while (e < kids.size() && kids[e].h == kids[i].h) e++;
+                // inside a run of equal hashes (almost always one string): a child survives iff no other triple spells the same string
+                for (size_t a = i; a < e; a++) {
+                    bool unique = true;
+                    for (size_t b = i; b < e && unique; b++)
+                        if (b != a && same_child(kids[a], kids[b])) unique = false;
+                    if (!unique) continue;
+                    const uint8_t *w = seqs + (size_t)kids[a].g * L;
+                    for (uint32_t k = 0; k < L; k++) child[k] = k == kids[a].j ? kids[a].b : w[k];
+                    if (lib_find(kids[a].h, child.data()) != SGC_NONE) continue;       // a library member is a parent: nulled (permutes.rs:149-152)
+                    kept[bk].push_back(kids[a]);
+                }
+                i = e;
+            }
         }
-        i = e;
+    };
+    auto run_threads = [&](const std::function<void(unsigned)> &f) {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < T; t++) th.emplace_back(f, t);
+        f(0);
+        for (auto &x : th) x.join();
+    };
+    run_threads(generate);
+    run_threads(screen);
+    std::vector<Kid> kids;                                                   // the survivors, in hash order
+    {
+        size_t total = 0;
+        for (auto &v : kept) total += v.size();
+        kids.reserve(total);
+        for (auto &v : kept) { kids.insert(kids.end(), v.begin(), v.end()); std::vector<Kid>().swap(v); }
     }
+    std::vector<size_t> keep(kids.size());
+    for (size_t i = 0; i < keep.size(); i++) keep[i] = i;
     out.perm_log2 = std::max<uint32_t>(4, ceil_log2((uint64_t)keep.size() * 2 + 1));
     out.perm_tag.assign((size_t)1 << out.perm_log2, SGC_BYTES_EMPTY);
     out.perm_val.assign((size_t)1 << out.perm_log2, SGC_NONE);
