@@ -1083,7 +1083,7 @@ static void count_fastq_scan(sgc_sample *smp, FastqScanner &scan, SampleStats *s
     if (st) {
         st->text_bytes = scan.file_size; st->reader_threads = scan.n_threads;
         st->read_busy_s = scan.busy_s; st->read_wait_s = scan.wait_s; st->push_s = t_push; st->upload_wait_s = t_upwait;
-        st->feeder_setup_s = t_a1 - t_a0; st->host_copy_s = t_copy; st->scan_path = true;
+        st->feeder_setup_s = t_a1 - t_a0; st->host_copy_s = t_copy; st->scan_path = true; st->scan_mapped = scan.used_mapping();
     }
 }
 
@@ -1202,7 +1202,7 @@ void count(const CountOptions &opt_in) {
         ScanParams sp;
         sp.L = (uint32_t)library.size; sp.reverse = opt.offsets[i].reverse; sp.offset = (uint32_t)opt.offsets[i].index;
         sp.recursion = opt.position_recursion;
-        return std::unique_ptr<FastqScanner>(new FastqScanner(opt.input_paths[i], sp, opt.scan_threads, opt.scan_block_bytes));
+        return std::unique_ptr<FastqScanner>(new FastqScanner(opt.input_paths[i], sp, opt.scan_threads, opt.scan_block_bytes, 16384, opt.scan_source));
     };
     if (packable)
         for (size_t i = 0; i < std::min(n_workers, opt.input_paths.size()); i++)
@@ -1313,11 +1313,11 @@ void count(const CountOptions &opt_in) {
                 n_dev, n_ctx, n_threads, per_dev.c_str());
         for (size_t i = 0; i < n; i++) {
             const SampleStats &x = stats[i];
-            fprintf(f, "%s{\"device\": %d, \"reads\": %llu, \"text_bytes\": %llu, \"gz\": %s, \"bgzf\": %s, \"parallel_gzip\": %s, \"gzip_chunks_decoded_in_order\": %zu, \"text_path\": %s, \"scan_path\": %s, \"host_copy_s\": %.6f, \"reader_threads\": %zu, "
+            fprintf(f, "%s{\"device\": %d, \"reads\": %llu, \"text_bytes\": %llu, \"gz\": %s, \"bgzf\": %s, \"parallel_gzip\": %s, \"gzip_chunks_decoded_in_order\": %zu, \"text_path\": %s, \"scan_path\": %s, \"scan_used_mapping\": %s, \"host_copy_s\": %.6f, \"reader_threads\": %zu, "
                        "\"wall_s\": %.6f, \"read_busy_s\": %.6f, \"wait_for_text_s\": %.6f, \"push_s\": %.6f, \"wait_for_upload_s\": %.6f, "
                        "\"finish_s\": %.6f, \"feeder_setup_s\": %.6f, \"first_push_s\": %.6f, \"h2d_ms\": %.3f, \"ingest_kernels_ms\": %.3f, \"count_kernels_ms\": %.3f}",
                     i ? ", " : "", sample_dev[i], (unsigned long long)x.reads, (unsigned long long)x.text_bytes, x.gz ? "true" : "false", x.bgzf ? "true" : "false", x.pgz ? "true" : "false", x.pgz_fallbacks,
-                    x.text_path ? "true" : "false", x.scan_path ? "true" : "false", x.host_copy_s, x.reader_threads, x.wall_s, x.read_busy_s, x.read_wait_s, x.push_s,
+                    x.text_path ? "true" : "false", x.scan_path ? "true" : "false", x.scan_mapped ? "true" : "false", x.host_copy_s, x.reader_threads, x.wall_s, x.read_busy_s, x.read_wait_s, x.push_s,
                     x.upload_wait_s, x.finish_s, x.feeder_setup_s, x.first_push_s, x.h2d_ms, x.ingest_ms, x.count_ms);
         }
         fprintf(f, "]}\n");

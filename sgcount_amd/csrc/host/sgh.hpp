@@ -15,6 +15,7 @@
 #pragma once
 #include <zlib.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <cstdint>
 #include <memory>
@@ -97,6 +98,7 @@ struct CountOptions {
     bool host_scan = true;               // plain FASTQ text + packable library: the host scans and packs (FastqScanner), 8 B/read are shipped
     size_t scan_threads = 0;             // scanner threads per sample (0 = min(16, usable CPUs - 1) / worker threads)
     size_t scan_block_bytes = 4u << 20;  // text per unit of scanner work
+    int scan_source = 1;                 // 1 the memory mapping (default: the same speed on a file written a moment ago), 2 pread(), 0 auto (FastqScanner)
     size_t chunk_bytes = 64u << 20;      // bytes of text per slice (one upload) for device_parse
     size_t io_threads = 0;               // reader threads per sample for plain FASTQ (0 = min(8, cores / worker threads))
     size_t inflate_threads = 0;          // inflating threads per BGZF sample (set with io_threads == 0: min(16, cores / worker threads))
@@ -115,6 +117,7 @@ struct SampleStats {                    // where one sample's wall time went (ho
     double h2d_ms = 0, ingest_ms = 0, count_ms = 0;
     double host_copy_s = 0;             // scan path: block records -> pinned buffers (consumer thread)
     bool scan_path = false;             // the host scanned and packed the text (FastqScanner); text_path: the GPU parsed it
+    bool scan_mapped = false;           // ... reading through the memory mapping (else pread() into the threads' buffers)
     double feeder_setup_s = 0, first_push_s = 0;   // pinned ring allocation + reader start; the first push (device scratch allocation)
     uint64_t text_bytes = 0, reads = 0;
     size_t reader_threads = 0;
@@ -206,7 +209,10 @@ class TextFeeder {
 struct ScanParams { uint32_t L = 0; bool reverse = false; uint32_t offset = 0; bool recursion = true; };
 class FastqScanner {
   public:
-    FastqScanner(const std::string &path, const ScanParams &prm, size_t threads, size_t block_bytes = 4u << 20, size_t max_ahead_blocks = 16384);
+    // source: where a block's bytes come from — 1 the mapping (page faults), 2 pread() into a buffer of the thread's own, 0 auto
+    // (pread, unless the threads' average read rate shows the first-read penalty of freshly written pages: then the mapping)
+    FastqScanner(const std::string &path, const ScanParams &prm, size_t threads, size_t block_bytes = 4u << 20, size_t max_ahead_blocks = 16384,
+                 int source = 0);
     ~FastqScanner();
     // the records of the next block (n_records records of `words` u64 each), in file order; false = end of file.  Throws
     // Panic on a malformed record (wrong marker byte; a line count that is no multiple of 4 at the end).
@@ -219,7 +225,14 @@ class FastqScanner {
   private:
     struct Block;
     void run();
-    void extract(size_t b);
+    void extract(size_t b, const uint8_t *t, size_t t_lo, size_t t_hi);
+    static constexpr size_t READ_SLACK = 64u << 10;      // bytes read behind a block: the rest of its last line, and the window loads
+    int source = 0;
+    std::atomic<bool> auto_map{false};
+    std::atomic<uint64_t> read_bytes{0}, read_ns{0};
+  public:
+    bool used_mapping() const { return source == 1 || auto_map.load(); }
+  private:
     std::string path;
     ScanParams prm;
     int fd = -1;

@@ -171,11 +171,11 @@ int sgh_text_feeder_walk(const char *path, uint64_t slice_bytes, uint64_t thread
 // the scan path's record source (sgh_scan.cpp FastqScanner): all records of a plain FASTQ file, in order.  usable_out = 0: the
 // scanner declines the file (not plain FASTQ text) and nothing is written.  cap = capacity of `out` in records.
 int sgh_scan_records(const char *path, uint32_t L, int reverse, uint32_t offset, int recursion, uint64_t threads, uint64_t block_bytes,
-                     uint64_t *out, uint64_t cap, uint64_t *n_out, uint64_t *lines_out, int *usable_out) {
+                     uint64_t *out, uint64_t cap, uint64_t *n_out, uint64_t *lines_out, int *usable_out, int source) {
     return guard([&] {
         sgh::ScanParams sp;
         sp.L = L; sp.reverse = reverse != 0; sp.offset = offset; sp.recursion = recursion != 0;
-        sgh::FastqScanner sc(path, sp, (size_t)threads, (size_t)block_bytes, 8);
+        sgh::FastqScanner sc(path, sp, (size_t)threads, (size_t)block_bytes, 8, source);
         *usable_out = sc.usable ? 1 : 0; *n_out = 0; *lines_out = 0;
         if (!sc.usable) return;
         const uint64_t *r; size_t n;

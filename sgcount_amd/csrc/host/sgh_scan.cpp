@@ -147,8 +147,9 @@ struct FastqScanner::Block {
     bool scanned = false, done = false;
 };
 
-FastqScanner::FastqScanner(const std::string &path_, const ScanParams &prm_, size_t threads, size_t block_bytes, size_t max_ahead)
+FastqScanner::FastqScanner(const std::string &path_, const ScanParams &prm_, size_t threads, size_t block_bytes, size_t max_ahead, int source_)
     : path(path_), prm(prm_) {
+    source = source_;
     fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) throw Error("No such file or directory (os error 2): " + path);
     struct stat sb;
@@ -199,15 +200,44 @@ void FastqScanner::run() {
             Block &blk = blocks[b];
             const size_t lo = b * block, hi = std::min(end, lo + block);
             const size_t map_hi = std::min(file_size, (hi + 4095) & ~(size_t)4095);
+            // Where the block's bytes come from: the mapping (default), or — options — a pread() into a buffer of the thread's own, which
+            // costs less than faulting the mapping in (a copy against a fault per 64 KiB: 0.30 against 0.39 s of busy time per thread
+            // on the 100M-read file, profiles/r03/e2e_scan_source.txt) UNLESS the file's pages were just written: then every first
+            // read() moves a page to the active LRU list under one lock and the same run takes 2.4 s instead of 0.6 (the head of this
+            // file).  "auto" starts with pread() and falls back to the mapping as soon as the threads' average read rate says so; it
+            // measured no better than the mapping alone, which is why the mapping is the default.
+            static thread_local std::vector<uint8_t> tbuf;
+            const uint8_t *t = map;                           // t[absolute offset], valid for offsets in [t_lo, t_hi)
+            size_t t_lo = 0, t_hi = file_size;
+            const bool by_read = source == 2 || (source == 0 && !auto_map.load(std::memory_order_relaxed));
+            if (by_read) {
+                const size_t a = lo ? lo - 1 : 0, z = std::min(end, hi + READ_SLACK), len = z - a;
+                if (tbuf.size() < len + 64) tbuf.resize(len + 64);
+                const double r0 = scan_now_s();
+                size_t got = 0;
+                while (got < len) {
+                    const ssize_t r = pread(fd, tbuf.data() + got, len - got, (off_t)(a + got));
+                    if (r < 0) throw Error("read error in " + path);
+                    if (r == 0) throw Error("file shrank while reading: " + path);
+                    got += (size_t)r;
+                }
+                memset(tbuf.data() + len, 0, 64);
+                const double dr = scan_now_s() - r0;
+                t = tbuf.data() - a; t_lo = a; t_hi = z;
+                if (source == 0) {
+                    const uint64_t nb = read_bytes.fetch_add(len) + len, ns_ = read_ns.fetch_add((uint64_t)(dr * 1e9)) + (uint64_t)(dr * 1e9);
+                    if (nb >= (64u << 20) && (double)nb / ((double)ns_ + 1.0) < 2.5) auto_map.store(true, std::memory_order_relaxed);      // < 2.5 GB/s per thread
+                }
+            }
             // phase 1: the lines that start in [lo, hi): after every '\n' at [lo - 1, hi - 1), and at 0
             blk.starts.reserve((hi - lo) / 64 + 16);
             if (b == 0) blk.starts.push_back(0);
             const size_t s_lo = lo ? lo - 1 : 0, s_hi = hi - 1;
 #if defined(__x86_64__)
-            if (have_avx2()) list_newlines_avx2(map, s_lo, s_hi, lo, blk.starts);
+            if (have_avx2()) list_newlines_avx2(t, s_lo, s_hi, lo, blk.starts);
             else
 #endif
-                list_newlines_generic(map, s_lo, s_hi, lo, blk.starts);
+                list_newlines_generic(t, s_lo, s_hi, lo, blk.starts);
             {
                 std::unique_lock<std::mutex> lk(mu);
                 blk.scanned = true;
@@ -220,8 +250,8 @@ void FastqScanner::run() {
                 cv.wait(lk, [&] { return stop || failed || chain > b; });
                 if (stop || failed) return;
             }
-            extract(b);
-            (void)madvise((void *)(map + lo), map_hi - lo, MADV_DONTNEED);      // drop the block's page-table entries here, in parallel, not at exit
+            extract(b, t, t_lo, t_hi);
+            if (!by_read) (void)madvise((void *)(map + lo), map_hi - lo, MADV_DONTNEED);      // drop the block's page-table entries here, in parallel, not at exit
             const double dt = scan_now_s() - t0;
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -237,8 +267,10 @@ void FastqScanner::run() {
     }
 }
 
-// phase 2 of block b
-void FastqScanner::extract(size_t b) {
+// phase 2 of block b; t[offset] is readable for offsets in [t_lo, t_hi) (the thread's buffer, or the mapping itself); what lies beyond
+// — the rest of a line longer than the slack behind the block — is taken from the mapping
+void FastqScanner::extract(size_t b, const uint8_t *t, size_t t_lo, size_t t_hi) {
+    (void)t_lo;
     Block &blk = blocks[b];
     const size_t lo = b * block;
     const size_t ns = blk.starts.size();
@@ -255,31 +287,39 @@ void FastqScanner::extract(size_t b) {
         const size_t s = lo + blk.starts[i];
         const uint32_t ph = (uint32_t)(g & 3u);
         if (ph == 0 || ph == 2) {
-            if (map[s] != (ph == 0 ? '@' : '+') && !blk.bad_line) blk.bad_line = g + 1;
+            if (t[s] != (ph == 0 ? '@' : '+') && !blk.bad_line) blk.bad_line = g + 1;
             continue;
         }
         if (ph == 3) continue;
         // sequence line [s, e)
         size_t e;
+        const uint8_t *src = t;                       // where this line's bytes are read from
+        size_t src_hi = t_hi;
         if (i + 1 < ns) e = lo + blk.starts[i + 1] - 1;
         else {
-            const void *q = memchr(map + s, '\n', end - s);
-            e = q ? (size_t)((const uint8_t *)q - map) : end;
+            const void *q = memchr(t + s, '\n', t_hi - s);
+            if (q) e = (size_t)((const uint8_t *)q - t);
+            else if (t_hi >= end) e = end;
+            else {                                    // the line runs past the thread's buffer: finish it on the mapping
+                src = map; src_hi = file_size;
+                const void *q2 = memchr(map + t_hi, '\n', end - t_hi);
+                e = q2 ? (size_t)((const uint8_t *)q2 - map) : end;
+            }
         }
         size_t n = e - s;
-        if (n && map[s + n - 1] == '\r') n--;
+        if (n && src[s + n - 1] == '\r') n--;
         uint64_t span = 0, status = 0;
         bool done = false;
 #if defined(__x86_64__)
         if (fast_ok && n >= (size_t)o + L + 1) {
             const size_t w0 = rev ? s + n - o - L - 1 : s + o - 1;           // first window byte in file order
-            if (w0 + 32 <= file_size) {
-                done = pack_fast_avx2(map + w0, K, rev, span);
+            if (w0 + 32 <= src_hi) {
+                done = pack_fast_avx2(src + w0, K, rev, span);
                 status = fast_status;
             }
         }
 #endif
-        if (!done) sgc_pack_one(map + s, n, L, rev ? 1 : 0, o, rec ? 1 : 0, span, status);
+        if (!done) sgc_pack_one(src + s, n, L, rev ? 1 : 0, o, rec ? 1 : 0, span, status);
         if (words == 2) { blk.recs.push_back(span); blk.recs.push_back(status); }
         else blk.recs.push_back(span | (status << sh));
     }

@@ -141,10 +141,11 @@ def text_feeder_drain(path, slice_bytes=32 << 20, threads=8, pgz_chunk=0):
     return nbytes.value, lines.value, busy.value, fb.value, ("bgzf" if k & 2 else "pgz" if k & 4 else "gz" if k & 1 else "plain")
 
 
-def scan_records(path, L, reverse=False, offset=0, recursion=True, threads=3, block_bytes=1 << 16, cap=None):
+def scan_records(path, L, reverse=False, offset=0, recursion=True, threads=3, block_bytes=1 << 16, cap=None, source=0):
     """All packed records of a plain FASTQ file as the scan path produces them (FastqScanner: memory-mapped text, several
     threads, blocks in order).  Returns (records as a uint64 array [n, words], total lines) or None if the scanner declines
-    the file (not plain FASTQ text).  Raises HostError 101 on a malformed / truncated record."""
+    the file (not plain FASTQ text).  Raises HostError 101 on a malformed / truncated record.  source: 0 auto, 1 the memory
+    mapping, 2 pread() into the threads' buffers."""
     words = 2 if L > 23 else 1
     if cap is None:
         cap = os.path.getsize(path) // 4 + 16          # a record takes at least 4 newlines... of text
@@ -152,7 +153,7 @@ def scan_records(path, L, reverse=False, offset=0, recursion=True, threads=3, bl
     n, lines, usable = C.c_uint64(), C.c_uint64(), C.c_int()
     _chk(load().sgh_scan_records(path.encode(), C.c_uint32(L), int(bool(reverse)), C.c_uint32(offset), int(bool(recursion)),
                                  C.c_uint64(threads), C.c_uint64(block_bytes), out.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                 C.c_uint64(cap), C.byref(n), C.byref(lines), C.byref(usable)))
+                                 C.c_uint64(cap), C.byref(n), C.byref(lines), C.byref(usable), int(source)))
     if not usable.value:
         return None
     return out[: n.value], lines.value

@@ -291,10 +291,10 @@ def test_scanner_records_equal_the_host_packer(tmp_path):
         for L, rev, o, rec in ((20, False, 30, True), (20, True, 30, True), (20, False, 0, True), (20, True, 1, False),
                                (23, False, 5, True), (24, True, 7, True), (30, False, 30, False), (4, False, 2, True)):
             want = _pack_host(seqs, L, rev, o, rec)
-            for threads, block in ((1, 1 << 22), (3, 4096), (4, 1 << 16)):
-                got, lines = hostlib.scan_records(str(p), L, rev, o, rec, threads=threads, block_bytes=block)
+            for threads, block, source in ((1, 1 << 22, 0), (3, 4096, 1), (4, 1 << 16, 2), (2, 4096, 2)):
+                got, lines = hostlib.scan_records(str(p), L, rev, o, rec, threads=threads, block_bytes=block, source=source)
                 assert lines == 4 * len(seqs)
-                assert got.shape == want.shape and np.array_equal(got, want), (eol, final_nl, tail, L, rev, o, rec, threads, block)
+                assert got.shape == want.shape and np.array_equal(got, want), (eol, final_nl, tail, L, rev, o, rec, threads, block, source)
     # the scanner declines what is not plain FASTQ text; malformed and truncated records panic (exit code 101)
     (tmp_path / "lib.fa").write_bytes(b">a\nACGT\n")
     assert hostlib.scan_records(str(tmp_path / "lib.fa"), 4) is None
