@@ -220,7 +220,11 @@ void sgc_free_pinned(void *p);
  * never more than a quarter of the device memory that is free at that moment —, times the partition kernel on each (under 1 ms
  * each; it stops at a candidate 11 % ahead of the slowest seen) and keeps the fastest: 10-30 ms once per ctx, which a single
  * sample never earns back; sgc_placement_info reports what the search did), "batch_records" (records per device-side batch of
- * sgc_sample_push_packed_async), "verbose" (diagnostics on stderr).  No environment
+ * sgc_sample_push_packed_async), "hybrid" (0: a library with a few guides outside ACGT is served by the byte-string path alone
+ * instead of the hybrid of both; next sgc_set_library), "host_routes" (1: in a hybrid ctx — sgc_lib_info.path == 2 — packed
+ * records are accepted after all: the host promises to push records ONLY for reads whose span region [o - 1, o + L + 1) is all
+ * ACGT and none of whose windows equals a guide with exactly one other byte up to that byte, and to push every other read as
+ * bytes (sgc_sample_push_reads); the C++ scanner does), "verbose" (diagnostics on stderr).  No environment
  * variable changes what the library computes or which kernels it runs.  "dbg" sets
  * timing-only ablation flags / phase stamps of the kernels: they are compiled out of the shipped library, which refuses
  * a non-zero value (a profiling build — SGC_HIPCC_FLAGS=-DSGC_ABLATE=1 or -DSGC_STAMPS=1 — accepts it; results are

@@ -1065,8 +1065,26 @@ static void count_fastq_scan(sgc_sample *smp, FastqScanner &scan, SampleStats *s
         sgc_check(sgc_sample_wait_uploads(smp, (uint32_t)(SCAN_BUFS - 1)), "sgc_sample_wait_uploads");
         t_upwait += now_s() - t0;
     };
+    // hybrid library: the reads the scanner set aside, gathered and pushed as bytes now and then (the byte-string chain)
+    std::vector<uint8_t> rbytes;
+    std::vector<uint64_t> roffs(1, 0);
+    auto push_routed = [&]() {
+        const uint64_t nr = roffs.size() - 1;
+        if (!nr) return;
+        const double t0 = now_s();
+        sgc_check(sgc_sample_push_reads(smp, rbytes.data(), roffs.data(), nr, SGC_MEM_HOST), "sgc_sample_push_reads");
+        sgc_check(sgc_sample_sync(smp), "sgc_sample_sync");            // the vectors are reused
+        t_push += now_s() - t0;
+        rbytes.clear(); roffs.resize(1);
+    };
     const uint64_t *recs; size_t n;
     while (scan.next(recs, n)) {
+        if (scan.n_routed) {
+            const uint64_t base = rbytes.size(), add = scan.routed_offs[scan.n_routed];
+            rbytes.insert(rbytes.end(), scan.routed_bytes, scan.routed_bytes + add);
+            for (size_t i = 1; i <= scan.n_routed; i++) roffs.push_back(base + scan.routed_offs[i]);
+            if (roffs.size() > (1u << 16)) push_routed();
+        }
         const double t0 = now_s();
         size_t done = 0;
         while (done < n) {
@@ -1079,6 +1097,7 @@ static void count_fastq_scan(sgc_sample *smp, FastqScanner &scan, SampleStats *s
         scan.release();
     }
     push();
+    push_routed();
     sgc_check(sgc_sample_wait_uploads(smp, 0), "sgc_sample_wait_uploads");         // the ring is freed on return
     if (st) {
         st->text_bytes = scan.file_size; st->reader_threads = scan.n_threads;
@@ -1097,7 +1116,8 @@ static SampleCounts count_sample(sgc_ctx *ctx, const std::string &path, const Of
     if (scan && scan->usable) {
         sgc_lib_info info;
         sgc_check(sgc_library_info(ctx, &info), "sgc_library_info");
-        if (info.record_bytes == scan->words * 8) { count_fastq_scan(smp, *scan, st); scanned = true; }
+        // (a hybrid ctx — path 2 — takes the scanner's records because the scanner routes the reads that need the byte-string chain)
+        if (info.record_bytes == scan->words * 8 || (info.path == 2 && scan->routes())) { count_fastq_scan(smp, *scan, st); scanned = true; }
     }
     scan.reset();
     const bool parsed_on_device = !scanned && opt.device_parse && opt.device_pack && count_fastq_text(smp, path, opt, st);
@@ -1195,13 +1215,21 @@ void count(const CountOptions &opt_in) {
     // the observable effects stays: a library or gene-map error was raised above, a malformed sample is reported when its
     // turn comes).
     bool packable = opt.host_scan && opt.device_pack && library.size >= 1 && library.size <= SGC_MAX_GUIDE_LEN;
+    size_t n_other = 0;                       // guides with a byte outside ACGT
     for (size_t i = 0; packable && i < library.seqs.size(); i++)
-        for (char ch : library.seqs[i]) if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') { packable = false; break; }
+        for (char ch : library.seqs[i]) if (ch != 'A' && ch != 'C' && ch != 'G' && ch != 'T') { n_other++; break; }
+    // a few such guides: the library becomes a hybrid ctx (sgc_set_library decides by the same rule) and the scanner routes the reads
+    // they could influence to the byte-string chain; more than half: the byte-string path alone, text parsed on the GPU
+    RouteFilter route_filter;
+    const bool hybrid = packable && n_other > 0 && n_other * 2 <= library.seqs.size() && n_other < library.seqs.size();
+    if (n_other && !hybrid) packable = false;
+    if (hybrid) route_filter = make_route_filter(library.seqs);
     std::vector<std::unique_ptr<FastqScanner>> scanners(opt.input_paths.size());
     auto make_scanner = [&](size_t i) {
         ScanParams sp;
         sp.L = (uint32_t)library.size; sp.reverse = opt.offsets[i].reverse; sp.offset = (uint32_t)opt.offsets[i].index;
         sp.recursion = opt.position_recursion;
+        sp.route = hybrid ? &route_filter : nullptr;
         return std::unique_ptr<FastqScanner>(new FastqScanner(opt.input_paths[i], sp, opt.scan_threads, opt.scan_block_bytes, 16384, opt.scan_source));
     };
     if (packable)
@@ -1252,6 +1280,7 @@ void count(const CountOptions &opt_in) {
     for (sgc_ctx *c : ctxs) {
         if (!opt.stats_path.empty()) sgc_check(sgc_timing_enable(c, 1), "sgc_timing_enable");
         sgc_check(sgc_set_option(c, "batch_records", (int64_t)(16 * SCAN_BUF_RECORDS)), "sgc_set_option");     // a whole number of pinned buffers
+        if (hybrid) sgc_check(sgc_set_option(c, "host_routes", 1), "sgc_set_option");      // this host sets the reads near the non-ACGT guides aside itself
     }
     const double t_tables = now_s();
     // samples in parallel (count.rs:117-136: rayon over samples, pool size -t), results in input order

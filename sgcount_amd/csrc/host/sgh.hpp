@@ -206,7 +206,14 @@ class TextFeeder {
 // blocks in file order (list the line starts, learn the block's first line number from the blocks before it, verify the
 // marker bytes, pack every sequence line's window into a record of sgc_format.h), the consumer takes the blocks' records
 // in order (the workers run at most max_ahead_blocks ahead of it: ~110 KB of records per 4 MiB block of 150-base reads).  usable == false: not a regular, non-empty file that starts with '@' (gzip, FASTA, a pipe): use the other readers.
-struct ScanParams { uint32_t L = 0; bool reverse = false; uint32_t offset = 0; bool recursion = true; };
+// hybrid libraries (a few guides with bytes outside ACGT): the Bloom filter of the shadow keys — the ACGT windows one substitution
+// away from a guide with exactly one such byte (same hashing as the device's: sgc_format.h sgc_hash2 / sgc_bloom_*); may be empty
+struct RouteFilter { std::vector<uint64_t> words; uint32_t log2_words = 0; };
+RouteFilter make_route_filter(const std::vector<std::string> &seqs);
+struct ScanParams {
+    uint32_t L = 0; bool reverse = false; uint32_t offset = 0; bool recursion = true;
+    const RouteFilter *route = nullptr;      // non-null: reads a non-ACGT guide could influence are set aside as bytes (next(): routed_*)
+};
 class FastqScanner {
   public:
     // source: where a block's bytes come from — 1 the mapping (page faults), 2 pread() into a buffer of the thread's own, 0 auto
@@ -218,6 +225,9 @@ class FastqScanner {
     // Panic on a malformed record (wrong marker byte; a line count that is no multiple of 4 at the end).
     bool next(const uint64_t *&recs, size_t &n_records);
     void release();                     // the block returned by the last next() may be dropped
+    // the reads of the block returned by the last next() that were set aside (ScanParams::route): n_routed reads, read i =
+    // routed_bytes[routed_offs[i], routed_offs[i + 1])
+    const uint8_t *routed_bytes = nullptr; const uint64_t *routed_offs = nullptr; size_t n_routed = 0;
     bool usable = true;
     size_t file_size = 0, n_threads = 0, words = 1;
     uint64_t total_lines = 0;           // after next() returned false
@@ -232,6 +242,7 @@ class FastqScanner {
     std::atomic<uint64_t> read_bytes{0}, read_ns{0};
   public:
     bool used_mapping() const { return source == 1 || auto_map.load(); }
+    bool routes() const { return prm.route != nullptr; }
   private:
     std::string path;
     ScanParams prm;

@@ -63,6 +63,27 @@ size_t usable_cpus() {
     return n;
 }
 
+// the shadow keys of the guides with exactly one byte outside ACGT (see sgc_bytes.hip): an ACGT window equal to such a guide
+// everywhere else is within one substitution of it; a guide with two or more such bytes is at distance >= 2 from every ACGT window
+RouteFilter make_route_filter(const std::vector<std::string> &seqs) {
+    RouteFilter f;
+    std::vector<uint64_t> keys;
+    for (const std::string &q : seqs) {
+        uint32_t bad = 0, at = 0;
+        for (uint32_t k = 0; k < q.size(); k++) if (!(q[k] == 'A' || q[k] == 'C' || q[k] == 'G' || q[k] == 'T')) { bad++; at = k; }
+        if (bad != 1 || q.size() > 32) continue;
+        uint64_t key = 0;
+        for (uint32_t k = 0; k < q.size(); k++) if (k != at) key |= (uint64_t)sgc_base_code((uint8_t)q[k]) << (2 * k);
+        for (uint64_t b = 0; b < 4; b++) keys.push_back(key | (b << (2 * at)));
+    }
+    if (keys.empty()) return f;
+    f.log2_words = 6;
+    while (f.log2_words < 20 && (1ull << f.log2_words) * 8 < keys.size() * 2 + 64) f.log2_words++;       // >= 32 bits per key
+    f.words.assign((size_t)1 << f.log2_words, 0);
+    for (uint64_t k : keys) { const uint64_t h2 = sgc_hash2(k); f.words[sgc_bloom_word(h2, f.log2_words)] |= sgc_bloom_mask(h2); }
+    return f;
+}
+
 // ---- line starts of a byte range ------------------------------------------------------------------------
 // appends p + 1 - base for every '\n' at p in [lo, hi)
 static void list_newlines_generic(const uint8_t *t, size_t lo, size_t hi, size_t base, std::vector<uint32_t> &out) {
@@ -145,6 +166,10 @@ struct FastqScanner::Block {
     uint64_t first_line = 0;           // global number of the block's first line
     uint64_t bad_line = 0;             // 1-based number of the first line whose marker byte is wrong (0 = none)
     bool scanned = false, done = false;
+    // hybrid library: the reads this block does NOT turn into records — a guide with bytes outside ACGT could influence them —, as
+    // bytes + offsets for the byte-string chain (sgc_sample_push_reads)
+    std::vector<uint8_t> routed_bytes;
+    std::vector<uint64_t> routed_offs;
 };
 
 FastqScanner::FastqScanner(const std::string &path_, const ScanParams &prm_, size_t threads, size_t block_bytes, size_t max_ahead, int source_)
@@ -320,6 +345,36 @@ void FastqScanner::extract(size_t b, const uint8_t *t, size_t t_lo, size_t t_hi)
         }
 #endif
         if (!done) sgc_pack_one(src + s, n, L, rev ? 1 : 0, o, rec ? 1 : 0, span, status);
+        if (prm.route) {
+            // hybrid library (sgc_bytes.hip k_bytes_route states the rule): a byte outside ACGT in the span region, or a window that
+            // hits the filter of the shadow keys, sends the read to the byte-string chain instead of the packed pass
+            bool route = false;
+            if (!done) {
+                for (uint32_t w = 0; w < K && !route; w++) {
+                    const int64_t pp = (int64_t)o - 1 + (int64_t)w;
+                    if (pp < 0 || (uint64_t)pp >= n) continue;
+                    const uint8_t ch = rev ? src[s + n - 1 - (size_t)pp] : src[s + (size_t)pp];
+                    route = !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T');
+                }
+            }
+            if (!route && !prm.route->words.empty()) {
+                const uint64_t kmask = sgc_key_mask(L);
+                const bool c_ok = (uint64_t)o + L <= n, p_ok = c_ok && rec && (uint64_t)o + 1 + L <= n, m_ok = p_ok && o >= 1;
+                const uint64_t keys[3] = {(span >> 2) & kmask, (span >> 4) & kmask, span & kmask};
+                const bool ok[3] = {c_ok, p_ok, m_ok};
+                for (int k = 0; k < 3 && !route; k++) {
+                    if (!ok[k]) continue;
+                    const uint64_t h2 = sgc_hash2(keys[k]), m = sgc_bloom_mask(h2);
+                    route = (prm.route->words[sgc_bloom_word(h2, prm.route->log2_words)] & m) == m;
+                }
+            }
+            if (route) {
+                if (blk.routed_offs.empty()) blk.routed_offs.push_back(0);
+                blk.routed_bytes.insert(blk.routed_bytes.end(), src + s, src + s + n);
+                blk.routed_offs.push_back(blk.routed_bytes.size());
+                continue;
+            }
+        }
         if (words == 2) { blk.recs.push_back(span); blk.recs.push_back(status); }
         else blk.recs.push_back(span | (status << sh));
     }
@@ -346,13 +401,21 @@ bool FastqScanner::next(const uint64_t *&recs, size_t &n_records) {
                     " does not start with its marker byte ('@' header / '+' separator) in " + path);
     recs = blk.recs.data();
     n_records = blk.recs.size() / words;
+    routed_bytes = blk.routed_bytes.data();
+    routed_offs = blk.routed_offs.data();
+    n_routed = blk.routed_offs.empty() ? 0 : blk.routed_offs.size() - 1;
     return true;
 }
 
 void FastqScanner::release() {
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (consumed < n_blocks) { std::vector<uint64_t>().swap(blocks[consumed].recs); consumed++; }
+        if (consumed < n_blocks) {
+            std::vector<uint64_t>().swap(blocks[consumed].recs);
+            std::vector<uint8_t>().swap(blocks[consumed].routed_bytes);
+            std::vector<uint64_t>().swap(blocks[consumed].routed_offs);
+            consumed++;
+        }
     }
     cv.notify_all();
 }

@@ -96,6 +96,7 @@ struct sgc_ctx {
     // reads a guide with other bytes could influence; d_gid_map: packed guide number -> library index; b_shadow: Bloom filter of the
     // shadow keys (the ACGT windows one substitution away from a guide with exactly one byte outside ACGT)
     bool hybrid = false, allow_hybrid = true;
+    bool host_routes = false;          // the host promises to push packed records only for reads no guide outside ACGT can influence
     uint32_t n_packed = 0;
     uint32_t *d_gid_map = nullptr;
     uint64_t *d_bloom_shadow = nullptr;
@@ -654,7 +655,7 @@ int sgc_ctx_clone(sgc_ctx *src, sgc_ctx **out) {
     c->variant = src->variant; c->per_lane = src->per_lane; c->k1_wgs = src->k1_wgs; c->max_chunk = src->max_chunk;
     c->batch_records = src->batch_records; c->dense = src->dense; c->direct = src->direct; c->six_byte = src->six_byte;
     c->five_byte = src->five_byte; c->tag_sub = src->tag_sub; c->use_cuckoo = src->use_cuckoo; c->place_trials = src->place_trials;
-    c->verbose = src->verbose;
+    c->verbose = src->verbose; c->host_routes = src->host_routes;
     *out = c;
     return SGC_OK;
 }
@@ -697,6 +698,7 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
     }
     if (!strcmp(key, "align_slices")) { c->align_slices = value != 0; return SGC_OK; }       // takes effect at the next sgc_set_library
     if (!strcmp(key, "force_bytes")) { c->force_bytes = value != 0; return SGC_OK; }         // takes effect at the next sgc_set_library
+    if (!strcmp(key, "host_routes")) { c->host_routes = value != 0; return SGC_OK; }
     if (!strcmp(key, "hybrid")) { c->allow_hybrid = value != 0; return SGC_OK; }             // 0: a library with any byte outside ACGT is served by the byte-string path alone (next sgc_set_library)
     if (!strcmp(key, "dense")) { c->dense = value != 0; return SGC_OK; }
     if (!strcmp(key, "direct")) { c->direct = value != 0; return SGC_OK; }
@@ -1165,7 +1167,7 @@ int sgc_sample_push_packed(sgc_sample *s, const void *records, uint64_t n, int w
     if (!s || (!records && n)) return fail(SGC_E_ARG, "sgc_sample_push_packed: NULL argument");
     if (n == 0) return SGC_OK;
     sgc_ctx *c = s->ctx;
-    if (c->bytes_mode || c->hybrid)
+    if (c->bytes_mode || (c->hybrid && !c->host_routes))
         return fail(SGC_E_STATE, "sgc_sample_push_packed: this library has no packed record format (sgc_library_info: record_bytes == 0); "
                                  "push reads or FASTQ text");
     HIP_TRY(hipSetDevice(c->device));
@@ -1201,7 +1203,7 @@ int sgc_sample_push_packed_async(sgc_sample *s, const void *records, uint64_t n)
     if (!s || (!records && n)) return fail(SGC_E_ARG, "sgc_sample_push_packed_async: NULL argument");
     if (n == 0) return SGC_OK;
     sgc_ctx *c = s->ctx;
-    if (c->bytes_mode || c->hybrid)
+    if (c->bytes_mode || (c->hybrid && !c->host_routes))
         return fail(SGC_E_STATE, "sgc_sample_push_packed_async: this library has no packed record format (sgc_library_info: record_bytes == 0)");
     HIP_TRY(hipSetDevice(c->device));
     const size_t rb = c->rec16 ? 16 : 8;

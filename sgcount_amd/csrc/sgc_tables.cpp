@@ -307,13 +307,6 @@ static uint64_t bytes_hash(const uint8_t *p, uint32_t L) {
     for (uint32_t i = 0; i < L; i++) h = sgc_bytes_hash_step(h, p[i]);
     return sgc_bytes_hash_fin(h);
 }
-// hash of `p` with p[j] replaced by b
-static uint64_t bytes_hash_sub(const uint8_t *p, uint32_t L, uint32_t j, uint8_t b) {
-    uint64_t h = sgc_bytes_hash_init();
-    for (uint32_t i = 0; i < L; i++) h = sgc_bytes_hash_step(h, i == j ? b : p[i]);
-    return sgc_bytes_hash_fin(h);
-}
-
 int sgc_build_bytes_tables(const uint8_t *seqs, uint32_t n, uint32_t L, bool one_mm, sgc_host_bytes &out, std::string &err) {
     if (L == 0 || L > SGC_BYTES_MAXL) { err = "guide length " + std::to_string(L) + " outside 1.." + std::to_string(SGC_BYTES_MAXL); return SGC_E_UNSUPPORTED; }
     if (n == 0) { err = "empty library"; return SGC_E_ARG; }

@@ -334,7 +334,24 @@ def test_hybrid_cli_table(tmp_path):
     for ident in lib.ids():
         row.append(0 if ident in seen else ctr.get_value(ident)); seen.add(ident)
     want = O.format_results(lib, [row], ["r"], None, False)
-    for path in (fq, fq + ".gz"):
-        p = subprocess.run([hostlib.cli_path(), "-l", lp, "-i", path, "-a", "9", "-q", "-n", "r"], capture_output=True, timeout=300)
+    import json
+    stats = str(tmp_path / "stats.json")
+    for path, extra, scan in ((fq, [], True), (fq, ["--pack", "fastq"], False), (fq + ".gz", [], False), (fq, ["--scan-threads", "3", "--scan-block-kb", "8"], True)):
+        p = subprocess.run([hostlib.cli_path(), "-l", lp, "-i", path, "-a", "9", "-q", "-n", "r", "--stats-json", stats] + extra, capture_output=True, timeout=300)
         assert p.returncode == 0, p.stderr.decode()
-        assert p.stdout.decode() == want
+        assert p.stdout.decode() == want, (path, extra)
+        assert json.load(open(stats))["samples"][0]["scan_path"] == scan      # plain text: the scanner routes the reads near the 'N' guides itself
+    # the other strand, no recursion, exact: the scanner's routing against the GPU's
+    rtext = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes((c ^ 4) if (c & 2) else (c ^ 21) for c in reversed(r)), b"I" * len(r)) for i, r in enumerate(reads))
+    open(fq, "wb").write(rtext)
+    for flags in (["-r"], ["-r", "-p"], ["-r", "-x"]):
+        outs = []
+        for extra in ([], ["--pack", "fastq"]):
+            p = subprocess.run([hostlib.cli_path(), "-l", lp, "-i", fq, "-a", "14", "-q", "-n", "r", "-z"] + flags + extra, capture_output=True, timeout=300)
+            assert p.returncode == 0, p.stderr.decode()
+            outs.append(p.stdout.decode())
+        ctr = O.Counter(lib, None if "-x" in flags else O.Permuter(lib), True, 14, 20, "-p" not in flags).feed_text(rtext)
+        seen, row = set(), []
+        for ident in lib.ids():
+            row.append(0 if ident in seen else ctr.get_value(ident)); seen.add(ident)
+        assert outs[0] == outs[1] == O.format_results(lib, [row], ["r"], None, True), flags
