@@ -437,6 +437,13 @@ def e2e_block(wl, args, exact, cpu):
                         "wall_s": w, "reads_per_s": s0["reads"] / w, "sample_s": s0["wall_s"], "table_build_s": st2["table_build_s"],
                         "count_kernels_s": s0["count_kernels_ms"] / 1e3, "ingest_kernels_s": s0["ingest_kernels_ms"] / 1e3,
                         "path": "host scan -> packed records (+ bytes of the routed reads)" if s0.get("scan_path") else "FASTQ text parsed on the GPU"}
+            # ... and the hybrid library on the whole sample, where the one-time table build hides behind the scan of the text
+            b2 = ["-l", libs["hybrid_100_N_guides"], "-a", "30", "-q", "-o", table] + (["-x"] if exact else [])
+            rr = [_run_cli(cli, b2 + ["-i", fq], stats=os.path.join(d, "stats_lib.json")) for _ in range(2)]
+            w, st2 = min(rr, key=lambda r: r[0])
+            legs["hybrid_100_N_guides"]["whole_sample"] = {"reads": int(st2["samples"][0]["reads"]), "wall_s": w, "reads_per_s": st2["samples"][0]["reads"] / w,
+                                                           "vs_acgt_library": out["plain"]["wall_s"] / w, "table_build_s": st2["table_build_s"],
+                                                           "sample_s": st2["samples"][0]["wall_s"]}
             out["non_acgt_libraries"] = dict(legs, reads=int(ngz),
                                              hybrid_vs_acgt=legs["hybrid_100_N_guides"]["default"]["reads_per_s"] / legs["acgt"]["default"]["reads_per_s"],
                                              hybrid_vs_acgt_sample_time=legs["acgt"]["default"]["sample_s"] / legs["hybrid_100_N_guides"]["default"]["sample_s"],

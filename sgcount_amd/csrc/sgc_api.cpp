@@ -774,7 +774,10 @@ static int upload_table(const sgc_host_table &h, uint64_t **d_slots, uint32_t **
 static int set_library_bytes(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32_t L, bool one_mm) {
     sgc_host_bytes hb;
     std::string err;
-    const int rc = sgc_build_bytes_tables(seqs, n, L, one_mm, hb, err);
+    // the children table (the 'Permuter' of the byte-string path) is built on the device where the device builder covers the
+    // library (sgc_build.hip: under 4M guides of under 128 bytes) — the host builder needs half a second for 100k guides of 20
+    const bool dev_children = one_mm && !c->host_build && sgc_device_bytes_children_supported(n, L);
+    const int rc = sgc_build_bytes_tables(seqs, n, L, one_mm && !dev_children, hb, err);
     if (rc != SGC_OK) return fail(rc, "sgc_set_library: " + err);
     hipError_t e = hipMalloc((void **)&c->d_bytes_seqs, (size_t)n * L);
     auto up = [&](void **d, const void *h, size_t bytes) {
@@ -784,10 +787,35 @@ static int set_library_bytes(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32
     if (e == hipSuccess) e = hipMemcpyAsync(c->d_bytes_seqs, seqs, (size_t)n * L, hipMemcpyHostToDevice, c->stream);
     up((void **)&c->d_bytes_tags[0], hb.lib_tag.data(), hb.lib_tag.size() * 8);
     up((void **)&c->d_bytes_vals[0], hb.lib_val.data(), hb.lib_val.size() * 4);
-    if (one_mm) {
+    uint32_t perm_log2 = hb.perm_log2;
+    void *d_scr = nullptr; unsigned long long *d_ent = nullptr;
+    if (one_mm && !dev_children) {
         up((void **)&c->d_bytes_tags[1], hb.perm_tag.data(), hb.perm_tag.size() * 8);
         up((void **)&c->d_bytes_vals[1], hb.perm_val.data(), hb.perm_val.size() * 4);
         up((void **)&c->d_bytes_pl, hb.perm_pl.data(), hb.perm_pl.size() * 4);
+    } else if (dev_children) {
+        // room for every child (n L 4 of them at most) at load <= 0.5, as the host builder sizes it for the children it keeps
+        perm_log2 = 4;
+        while ((1ull << perm_log2) < (uint64_t)n * L * 4u * 2u + 1u) perm_log2++;
+        const size_t slots = (size_t)1 << perm_log2;
+        if (e == hipSuccess) e = hipMalloc((void **)&c->d_bytes_tags[1], slots * 8);
+        if (e == hipSuccess) e = hipMalloc((void **)&c->d_bytes_vals[1], slots * 4);
+        if (e == hipSuccess) e = hipMalloc((void **)&c->d_bytes_pl, slots * 4);
+        if (e == hipSuccess) e = hipMalloc(&d_scr, sgc_device_bytes_children_scratch(n, L));
+        if (e == hipSuccess) e = hipMalloc((void **)&d_ent, 8);
+        if (e == hipSuccess) e = hipMemsetAsync(c->d_bytes_tags[1], 0xFF, slots * 8, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_ent, 0, 8, c->stream);
+        if (e == hipSuccess) {
+            const sgc_bytes_view v0{c->d_bytes_seqs, c->d_bytes_tags[0], c->d_bytes_vals[0], nullptr, nullptr, nullptr, n, L, hb.lib_log2, perm_log2};
+            if (sgc_device_bytes_children(c->stream, v0, c->d_bytes_tags[1], c->d_bytes_vals[1], c->d_bytes_pl, perm_log2, d_ent, d_scr) != 0) e = hipErrorUnknown;
+        }
+        unsigned long long ent = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&ent, d_ent, 8, hipMemcpyDeviceToHost, c->stream);
+        const hipError_t e3 = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = e3;
+        hb.perm_entries = ent;
+        if (d_scr) hipFree(d_scr);
+        if (d_ent) hipFree(d_ent);
     }
     const hipError_t e2 = hipStreamSynchronize(c->stream);          // the host vectors must outlive the copies
     if (e == hipSuccess) e = e2;
@@ -796,7 +824,7 @@ static int set_library_bytes(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint32
         return fail(e == hipErrorOutOfMemory ? SGC_E_OOM : SGC_E_HIP, std::string("sgc_set_library: ") + hipGetErrorString(e));
     }
     c->v_bytes = sgc_bytes_view{c->d_bytes_seqs, c->d_bytes_tags[0], c->d_bytes_vals[0], c->d_bytes_tags[1], c->d_bytes_vals[1], c->d_bytes_pl,
-                                n, L, hb.lib_log2, hb.perm_log2};
+                                n, L, hb.lib_log2, perm_log2};
     c->perm_entries = hb.perm_entries;
     c->bytes_mode = true;
     c->n = n; c->L = L; c->one_mm = one_mm; c->rec16 = false;

@@ -113,6 +113,13 @@ int sgc_device_build_permute(hipStream_t st, const uint64_t *d_keys, uint32_t n,
 // bit 31 of every guide id of a core index := "this guide has an ambiguous child" (after d_amb is complete on the stream)
 void sgc_flag_ambiguous(hipStream_t st, uint32_t *d_gids, uint64_t n_entries, const uint64_t *d_amb);
 
+// the children table of the byte-string path on the device (sgc_build.hip; the host builder is sgc_tables.cpp sgc_build_bytes_tables)
+struct sgc_bytes_view;
+bool sgc_device_bytes_children_supported(uint32_t n, uint32_t L);
+size_t sgc_device_bytes_children_scratch(uint32_t n, uint32_t L);
+int sgc_device_bytes_children(hipStream_t st, const sgc_bytes_view &v, uint64_t *perm_tag, uint32_t *perm_val, uint32_t *perm_pl, uint32_t perm_log2,
+                              unsigned long long *d_entries, void *d_scratch);
+
 // ---- FASTQ ingest (sgc_fastq.hip) -----------------------------------------------------------------
 // tile_scratch: sgc_fastq_tiles(n) + 1 u32.  sgc_launch_fastq_count leaves the newlines before every tile there and
 // tile_scratch[tiles] = number of '\n' in the text; sgc_launch_fastq_pack then writes the records of the part's
