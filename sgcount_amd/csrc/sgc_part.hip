@@ -46,6 +46,10 @@
                                  // 1024-record blocks a sixth of all slots of a 100M-read pass is empty, and k_count_slices pays for
                                  // every block it walks, full or not (k1_wgs 256 instead of 512 halves the open blocks: K2 0.276 ->
                                  // 0.243 ms, but K1 then runs one workgroup per CU); smaller blocks do the same without that price
+#ifndef PART_PAD
+#define PART_PAD 0u              // experiment (DESIGN.md §6 "placement"): u64 words of padding behind every block of the pool
+#endif
+#define PART_STRIDE (PART_BLOCK + PART_PAD)      // distance between blocks of the pool, in 8-byte words
 #define PART_MAXP 128u           // max library slices (~210k guides); partition index P_lib is the generic one
 #define PART_ARR (PART_MAXP + 1u)
 #define DESC_FILL_MASK 0xFFFFu
@@ -248,12 +252,12 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
             char *pb = reinterpret_cast<char *>(pool);
             if (!SGC_BOUND((at >> PART_LOG2_BLOCK) < gridDim.x * blocks_per_wg, err, 8)) continue;
             if ((p6 || p5) && p != P) {
-                const uint32_t bo = (at >> PART_LOG2_BLOCK) << (PART_LOG2_BLOCK + 3u), idx = (at + part_rot(at >> PART_LOG2_BLOCK)) & (PART_BLOCK - 1u);
+                const uint32_t bo = (at >> PART_LOG2_BLOCK) * (PART_STRIDE * 8u), idx = (at + part_rot(at >> PART_LOG2_BLOCK)) & (PART_BLOCK - 1u);
                 *reinterpret_cast<uint32_t *>(pb + (size_t)(bo + (idx << 2))) = (uint32_t)r;
                 if (p5) *reinterpret_cast<uint8_t *>(pb + (size_t)(bo + P6_HI_OFF + idx)) = (uint8_t)(r >> 32);
                 else *reinterpret_cast<uint16_t *>(pb + (size_t)(bo + P6_HI_OFF + (idx << 1))) = (uint16_t)(r >> 32);
             } else {
-                *reinterpret_cast<uint64_t *>(pb + (size_t)(at << 3)) = r;
+                *reinterpret_cast<uint64_t *>(pb + (size_t)(((at >> PART_LOG2_BLOCK) * PART_STRIDE + (at & (PART_BLOCK - 1u))) << 3)) = r;
             }
         }
         __syncthreads();
@@ -280,8 +284,8 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
 // REC: 0 = 8-byte records, 1 = six-byte, 2 = five-byte blocks
 template <int REC>
 __device__ __forceinline__ uint64_t k2_record(const uint64_t *__restrict__ pool, uint32_t b, uint32_t j) {
-    if (REC == 0) return pool[(uint64_t)b * PART_BLOCK + j];
-    const char *bb = reinterpret_cast<const char *>(pool) + (uint64_t)b * (PART_BLOCK * 8u);
+    if (REC == 0) return pool[(uint64_t)b * PART_STRIDE + j];
+    const char *bb = reinterpret_cast<const char *>(pool) + (uint64_t)b * (PART_STRIDE * 8u);
     j = (j + part_rot(b)) & (PART_BLOCK - 1u);
     const uint32_t lo = reinterpret_cast<const uint32_t *>(bb)[j];
     const uint32_t hi = REC == 2 ? (uint32_t)reinterpret_cast<const uint8_t *>(bb + P6_HI_OFF)[j] : (uint32_t)reinterpret_cast<const uint16_t *>(bb + P6_HI_OFF)[j];
@@ -476,7 +480,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                     if (mv) mrun[(uint64_t)run0 + pos] = cur[q] & PART_TAG_MASK;
                 } else {
                     const uint32_t pos = atomicAdd(mv ? &miss_cnt[par][u * BPS + h] : &scratch[64u + (t & 63u)], 1u);
-                    if (mv) pool[(uint64_t)(ce[u] >> 11) * PART_BLOCK + ((part_front(ce[u] >> 11) + pos) & (PART_BLOCK - 1u))] = cur[q] & PART_TAG_MASK;
+                    if (mv) pool[(uint64_t)(ce[u] >> 11) * PART_STRIDE + ((part_front(ce[u] >> 11) + pos) & (PART_BLOCK - 1u))] = cur[q] & PART_TAG_MASK;
                 }
             }
 #pragma unroll
@@ -581,7 +585,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                     uint64_t r[8];
 #pragma unroll
                     for (uint32_t k = 0; k < 8; k++)
-                        if (j < (e[k] & 2047u)) r[k] = pool[(uint64_t)(e[k] >> 11) * PART_BLOCK + ((part_front(e[k] >> 11) + j) & (PART_BLOCK - 1u))];
+                        if (j < (e[k] & 2047u)) r[k] = pool[(uint64_t)(e[k] >> 11) * PART_STRIDE + ((part_front(e[k] >> 11) + j) & (PART_BLOCK - 1u))];
 #pragma unroll
                     for (uint32_t k = 0; k < 8; k++) {
                         if (j >= (e[k] & 2047u)) continue;
@@ -598,7 +602,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 for (uint32_t k = 0; k < 4; k++) {
                     const uint32_t e = i0 + k < ng ? glist[i0 + k] : 0u;
                     f[k] = e & 2047u;
-                    if (t < f[k]) r[k] = pool[(uint64_t)(e >> 11) * PART_BLOCK + t];
+                    if (t < f[k]) r[k] = pool[(uint64_t)(e >> 11) * PART_STRIDE + t];
                 }
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) {
@@ -681,7 +685,7 @@ __global__ void __launch_bounds__(K3_THREADS) k_resolve_miss(const uint64_t *__r
         __syncthreads();
         for (uint32_t u = t >> 6; u < K3_SEG; u += K3_THREADS / 64) {
             const uint32_t lane = t & 63u;
-            const uint64_t *blkp = pool + (uint64_t)(b0 + u) * PART_BLOCK;
+            const uint64_t *blkp = pool + (uint64_t)(b0 + u) * PART_STRIDE;
             const uint32_t fr = part_front(b0 + u);
             for (uint32_t j = lane; j < m_[u]; j += 64) {
                 const uint32_t d = off_[u] + j;
@@ -797,7 +801,7 @@ __global__ void __launch_bounds__(256) k_generic(const uint64_t *__restrict__ po
         const uint32_t d = desc[b];
         if ((d >> 16) != p_generic + 1) continue;
         const uint32_t m = d & DESC_FILL_MASK;
-        const uint64_t *blkp = pool + (uint64_t)b * PART_BLOCK;
+        const uint64_t *blkp = pool + (uint64_t)b * PART_STRIDE;
         for (uint32_t j = t; j < m; j += 256) {
             const uint64_t rec = blkp[j];
             const uint32_t x = sgc_assign<true>(rec & smask, rec >> sh, L, lib, perm, ONE_MM);
@@ -864,7 +868,7 @@ void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_
     g->per_wg = per;
     g->blocks_per_wg = (uint32_t)(per / PART_BLOCK) + P + 1;           // full blocks + one open block per partition (incl. generic)
     g->n_blocks = wgs * g->blocks_per_wg;
-    g->pool_bytes = (uint64_t)g->n_blocks * PART_BLOCK * 8;
+    g->pool_bytes = (uint64_t)g->n_blocks * PART_STRIDE * 8;
     g->desc_tail_off = ((uint64_t)g->n_blocks * 4 + 255) & ~255ull;
     g->wcnt_off = g->desc_tail_off + SGC_DESC_TAIL;          // k_partition zeroes the tail and writes every wcnt entry
     g->wlist_off = (g->wcnt_off + (uint64_t)wgs * PART_ARR * 4 + 255) & ~255ull;
