@@ -17,6 +17,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(1024) k_fill(u32x4 *dst, size_t n16) {
     for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 1024) dst[i] = u32x4{1, 2, 3, (uint32_t)i};
 }
+__global__ void __launch_bounds__(1024) k_fill_nt(u32x4 *dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 1024) __builtin_nontemporal_store(u32x4{1, 2, 3, (uint32_t)i}, &dst[i]);
+}
+__global__ void __launch_bounds__(1024) k_copy_nt(const u32x4 *src, u32x4 *dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 1024) __builtin_nontemporal_store(__builtin_nontemporal_load(&src[i]), &dst[i]);
+}
 __global__ void __launch_bounds__(1024) k_sum(const u32x4 *src, size_t n16, uint32_t *out) {
     uint32_t s = 0;
     for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 1024) { u32x4 v = __builtin_nontemporal_load(&src[i]); s += v.x ^ v.y ^ v.z ^ v.w; }
@@ -63,7 +69,7 @@ int main() {
     prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = 0;
     size_t gran = 0;
     if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) == hipSuccess && gran) {
-        for (size_t chunk : {gran, (size_t)(2u << 20), (size_t)(32u << 20)}) {
+        for (size_t chunk : {(size_t)(2u << 20), (size_t)(32u << 20)}) {
             if (chunk % gran) continue;
             const size_t n_chunks = N / chunk;
             void *va = nullptr;
@@ -87,6 +93,9 @@ int main() {
     const size_t n16 = N / 16;
     for (auto &b : bufs) {
         const float f = time_it(st, 10, [&] { hipLaunchKernelGGL(k_fill, dim3(2048), dim3(1024), 0, st, (u32x4 *)b.p, n16); });
+        const float fnt = time_it(st, 10, [&] { hipLaunchKernelGGL(k_fill_nt, dim3(2048), dim3(1024), 0, st, (u32x4 *)b.p, n16); });
+        const float cnt = time_it(st, 10, [&] { hipLaunchKernelGGL(k_copy_nt, dim3(2048), dim3(1024), 0, st, (const u32x4 *)src, (u32x4 *)b.p, n16); });
+        printf("%-26s fill with nontemporal stores %.2f TB/s  copy-into with nontemporal stores %.2f TB/s (r+w)\n", b.name, N / fnt / 1e9, 2.0 * N / cnt / 1e9);
         const float s = time_it(st, 10, [&] { hipLaunchKernelGGL(k_sum, dim3(2048), dim3(1024), 0, st, (const u32x4 *)b.p, n16, flag); });
         const float cp = time_it(st, 10, [&] { hipLaunchKernelGGL(k_copy, dim3(2048), dim3(1024), 0, st, (const u32x4 *)src, (u32x4 *)b.p, n16); });
         const float cr = time_it(st, 10, [&] { hipLaunchKernelGGL(k_copy, dim3(2048), dim3(1024), 0, st, (const u32x4 *)b.p, (u32x4 *)src, n16); });
