@@ -26,6 +26,9 @@ extern "C" {
 
 #define SGS_MODE_FIXED 0
 #define SGS_MODE_STAGGER 1
+/* | SGS_MODE_DOMINANT(pct): pct (1..99) percent of the reads draw ONE guide (index 7 % n) instead of the weighted pick — a sample
+ * that a single guide dominates */
+#define SGS_MODE_DOMINANT(pct) (((unsigned)(pct) & 127u) << 8)
 #define SGS_READ_LEN 150
 #define SGS_PREFIX_LEN 30
 

@@ -111,6 +111,8 @@ struct sgc_ctx {
     sgc_bytes_view v_bytes{};
     void *d_cbuf = nullptr; size_t cbuf_cap = 0;        // two record buffers of the core passes
     void *d_csmall = nullptr; size_t csmall_cap = 0;    // their histograms / partition starts / extents
+    uint32_t *d_slice_tot = nullptr;                    // 2 x SGC_SLICE_TOT words: blocks per slice of this pass | zeroed for the next (balanced shares)
+    int tot_parity = 0, balanced = 1;
     // scratch (grown on demand, stream-ordered reuse)
     void *d_stage = nullptr; size_t stage_cap = 0;      // host -> device staging of pushed buffers
     // FASTQ text pushed from host memory: uploads run on their own stream into two alternating device buffers, so that
@@ -341,19 +343,30 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n, bool
             // direct runs: the misses go straight to per-partition runs inside one allocation with pass A's other input
             // (runs region | miss runs | forward buffer); the run matrices get one more column per workgroup of a slice.
             // With them nothing but the probe loop reads the slice blocks, which then hold six-byte records if they fit.
-            const bool direct = core_path && c->dense && c->direct && tag_sub && sgc_part_k2_grid(g) + sgc_part_k2_shares(g) <= 1024u;
+            // (the run matrices have at most 1024 columns: one per workgroup for its share of the generic blocks + the direct runs' —
+            // balanced shares: any workgroup may meet any slice; static shares: the workgroups of one slice)
+            const bool direct = core_path && c->dense && c->direct && tag_sub &&
+                                sgc_part_k2_grid(g) + sgc_part_k2_direct_cols(g, c->balanced != 0) <= 1024u;
+            const bool bal = direct && c->balanced;
+            if (bal && !c->d_slice_tot) {
+                HIP_TRY(hipMalloc((void **)&c->d_slice_tot, 2 * SGC_SLICE_TOT * 4));
+                HIP_TRY(hipMemsetAsync(c->d_slice_tot, 0, 2 * SGC_SLICE_TOT * 4, c->stream));
+                c->tot_parity = 0;
+            }
+            uint32_t *const tot = bal ? c->d_slice_tot + SGC_SLICE_TOT * c->tot_parity : nullptr;
+            uint32_t *const tot_next = bal ? c->d_slice_tot + SGC_SLICE_TOT * (c->tot_parity ^ 1) : nullptr;
             // what the slice blocks hold: 2 = five-byte records (the slice index is a prefix of the mixed core value, so a record keeps
             // 2 (L + 2) - slice bits <= 40 bits), 1 = six-byte records (span + sub-partition <= 48 bits), 0 = whole 8-byte records
             const uint32_t slice_bits = c->v_lib.log2_slots - c->v_lib.log2_slice;
             const int six = !direct ? 0 :
                             (c->five_byte && 2u * (c->L + 2u) - slice_bits <= 40u && slice_bits + (uint32_t)sub <= 2u * c->v_lib.core_cl) ? 2 :
                             (c->six_byte && 2u * (c->L + 2u) + 2u <= 48u) ? 1 : 0;
-            { timed t(c, T_PART); sgc_launch_part_k1(c->stream, s->d_err + 1, p, chunk, c->L, c->v_lib, tag_sub ? (uint32_t)sub : 0u, g, pool, desc, six); }
+            { timed t(c, T_PART); sgc_launch_part_k1(c->stream, s->d_err + 1, p, chunk, c->L, c->v_lib, tag_sub ? (uint32_t)sub : 0u, g, pool, desc, six, c->dbg, tot); }
             if (core_path) {
                 // everything the slice probe does not settle (its misses + the generic partition) is resolved in LDS by the
                 // two core passes; k_count_slices itself lays those records out as pass A's runs
                 sgc_core_geometry cg;
-                sgc_core_plan(chunk, c->v_core[0], c->v_core[1], sgc_part_k2_grid(g) + (direct ? sgc_part_k2_shares(g) : 0u), &cg);
+                sgc_core_plan(chunk, c->v_core[0], c->v_core[1], sgc_part_k2_grid(g) + (direct ? sgc_part_k2_direct_cols(g, bal) : 0u), &cg);
                 const size_t mrun_bytes = c->dense ? (size_t)g.pool_bytes << (direct ? (uint32_t)sub : 0u) : 0;
                 rc = ensure(&c->d_cbuf, &c->cbuf_cap, (size_t)(cg.runs_a_bytes + mrun_bytes + cg.fwd_bytes), c->device, c->vmm_runs ? c->vmm_chunk : 0);
                 if (rc) return rc;
@@ -385,7 +398,7 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n, bool
                         cand &cd = cands.back();
                         for (int rep = 0; rep < 2; rep++) {
                             if (rep) ok = ok && hipEventRecord(e0, c->stream) == hipSuccess;
-                            sgc_launch_part_k1(c->stream, s->d_err + 1, p, chunk, c->L, c->v_lib, (uint32_t)sub, g, (uint64_t *)cd.pool, desc, six);
+                            sgc_launch_part_k1(c->stream, s->d_err + 1, p, chunk, c->L, c->v_lib, (uint32_t)sub, g, (uint64_t *)cd.pool, desc, six, c->dbg, nullptr);
                         }
                         ok = ok && hipEventRecord(e1, c->stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
                              hipEventElapsedTime(&cd.ms, e0, e1) == hipSuccess;
@@ -412,7 +425,8 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n, bool
                     pool = (uint64_t *)c->d_pool;
                     HIP_TRY(hipGetLastError());
                     // the real pass starts over on the chosen pool
-                    { timed t(c, T_PART); sgc_launch_part_k1(c->stream, s->d_err + 1, p, chunk, c->L, c->v_lib, tag_sub ? (uint32_t)sub : 0u, g, pool, desc, six); }
+                    if (tot) HIP_TRY(hipMemsetAsync(tot, 0, SGC_SLICE_TOT * 4, c->stream));
+                    { timed t(c, T_PART); sgc_launch_part_k1(c->stream, s->d_err + 1, p, chunk, c->L, c->v_lib, tag_sub ? (uint32_t)sub : 0u, g, pool, desc, six, c->dbg, tot); }
                 }
                 uint64_t *buf0 = (uint64_t *)c->d_cbuf, *mrun = c->dense ? (uint64_t *)((char *)c->d_cbuf + cg.runs_a_bytes) : nullptr;
                 uint64_t *buf1 = (uint64_t *)((char *)c->d_cbuf + cg.runs_a_bytes + mrun_bytes);
@@ -421,7 +435,8 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n, bool
                 if (tag_sub) ra.sub_bits = (uint32_t)sub;
                 uint32_t *mcur = (uint32_t *)zeroed + 2 * RUN_MAXP + 2;        // behind totals A | totals B | region cursors (zeroed by K1)
                 { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, c32, s->d_matched, c->dbg, &ra,
-                                                                 c->use_cuckoo ? c->d_lib_cuckoo : nullptr, mrun, mcur, direct, six); }
+                                                                 c->use_cuckoo ? c->d_lib_cuckoo : nullptr, mrun, mcur, direct, six, tot, tot_next); }
+                if (bal) c->tot_parity ^= 1;
                 // timing: miss_ms = core pass A (+ its epilogue), hist_ms = core pass B
                 if (!c->one_mm) {
                     timed t(c, T_MISS, true);
@@ -439,7 +454,7 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n, bool
                 if (done < n) fold_counts(s);
                 continue;
             }
-            { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, c32, s->d_matched, c->dbg, nullptr, c->use_cuckoo ? c->d_lib_cuckoo : nullptr, nullptr, nullptr, false, 0); }
+            { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, c32, s->d_matched, c->dbg, nullptr, c->use_cuckoo ? c->d_lib_cuckoo : nullptr, nullptr, nullptr, false, 0, nullptr, nullptr); }
             rc = ensure(&c->d_gids, &c->gids_cap, g.gids_bytes);                // one slot per pool record: every read may miss
             if (rc) return rc;
             rc = ensure(&c->d_aux, &c->aux_cap, ((size_t)g.n_segs + 1) * 4);
@@ -618,6 +633,7 @@ void sgc_free(sgc_ctx *c) {
     dev_free(c->d_desc);
     dev_free(c->d_cbuf);
     dev_free(c->d_csmall);
+    if (c->d_slice_tot) (void)hipFree(c->d_slice_tot);
     if (c->side_stream) { hipStreamSynchronize(c->side_stream); hipStreamDestroy(c->side_stream); }
     if (c->copy_stream) { hipStreamSynchronize(c->copy_stream); hipStreamDestroy(c->copy_stream); }
     for (int i = 0; i < 2; i++) { dev_free(c->d_text[i]); if (c->ev_use[i]) hipEventDestroy(c->ev_use[i]); }
@@ -686,6 +702,13 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
         if (value && !(SGC_ABLATE || SGC_STAMPS_BUILD))
             return fail(SGC_E_ARG, "sgc_set_option: dbg flags need a library built with -DSGC_ABLATE=1 or -DSGC_STAMPS=1 (SGC_HIPCC_FLAGS; tools/tune.py --ablate)");
         c->dbg = (uint32_t)value; return SGC_OK;
+    }
+    if (!strcmp(key, "balanced")) { c->balanced = value != 0; return SGC_OK; }      // k_count_slices: equal shares of all slice blocks (1) or of each slice's (0)
+    if (!strcmp(key, "timeline_dump")) {
+        // -DSGC_STAMPS=1 builds: print (and clear) the workgroup timelines the kernels of the LAST pass left with dbg 1048576 (sgc_device.h)
+        if (!SGC_STAMPS_BUILD) return fail(SGC_E_ARG, "sgc_set_option: timeline_dump needs a library built with -DSGC_STAMPS=1");
+        sgc_part_timeline_dump(); sgc_core_timeline_dump(); fflush(stdout);
+        return SGC_OK;
     }
     if (!strcmp(key, "k1_wgs")) { c->k1_wgs = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(value, 65536)); return SGC_OK; }
     if (!strcmp(key, "max_chunk")) {
@@ -1432,7 +1455,7 @@ static int check_fastq_errors(sgc_sample *s) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (SGC_CHECK && (e[1] >> 8))
         return fail(SGC_E_STATE, "internal bounds check failed in the partitioned pass (flags " + std::to_string(e[1] >> 8) +
-                                     ": 1 pool write, 2 block id, 4 block fill, 8 miss-run slot)");
+                                     ": 1 pool write, 2 block id, 4 block fill, 8 miss-run slot, 16 slice totals)");
     if (e[1] & 1ull) return fail(SGC_E_FORMAT, "FASTQ text: the newline count announced for a part differs from its contents");
     if (e[0]) return fail(SGC_E_FORMAT, "malformed FASTQ record: line " + std::to_string(~0ull - e[0]) +
                                            " does not start with its marker byte ('@' header / '+' separator)");

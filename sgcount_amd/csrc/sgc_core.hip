@@ -63,6 +63,15 @@ __device__ __forceinline__ void starts_from_totals(const uint32_t *__restrict__ 
     __syncthreads();
 }
 
+#if SGC_STAMPS
+static __device__ sgc_tl_row tl_core[2][SGC_TL_MAXWG];
+#endif
+void sgc_core_timeline_dump() {
+#if SGC_STAMPS
+    SGC_TIMELINE_DUMP(tl_core[0], "coreA"); SGC_TIMELINE_DUMP(tl_core[1], "coreB");
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------ resolver
 // A partition's records (the concatenation of the segments the producers left for it, in.cnt / in.off row p) are cut
 // into chunks of KC_CHUNK; workgroup w of KC_GRID takes the w-th equal share of the chunk list of all partitions — a
@@ -84,6 +93,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     uint64_t *__restrict__ fwd, const sgc_runs out, uint32_t *__restrict__ counts, unsigned long long *__restrict__ matched,
     uint32_t dbg) {
     const uint32_t L = LT ? (uint32_t)LT : L_arg;
+    SGC_TIMELINE_BEGIN(dbg);
     if (LT) {
         // the cores are a function of L alone (sgc_api.cpp: A = [2, 2 + (L - 2) / 2), B = the rest of [2, L)); pass B is FINAL && !EXACT
         constexpr uint32_t ca = LT ? ((uint32_t)LT - 2u) / 2u : 0u;
@@ -349,6 +359,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             }
         }
     }
+    SGC_TIMELINE_END(dbg, tl_core[FINAL ? 1 : 0], c_hi - c_lo);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -396,7 +407,7 @@ void sgc_launch_core(hipStream_t st, int pass, uint32_t L, const sgc_table_view 
     // the specialisation for L = 20 needs the cores where it expects them (they are: sgc_set_library cuts them that way)
     const bool l20 = L == 20 && ca.cs == 2 && ca.cl == 9 && cb.cs == 11 && cb.cl == 9;
 #define KC_LAUNCH(FINAL, EXACT, LT, IN, CV, FWD, OUT)                                                                        \
-    hipLaunchKernelGGL((k_core<FINAL, EXACT, LT>), dim3(KC_GRID), dim3(KC_THREADS), 0, st, IN, CV, am, L, lib, perm, FWD, OUT, counts, matched, dbg)
+    hipLaunchKernelGGL((k_core<FINAL, EXACT, LT>), dim3(KC_GRID), dim3(KC_THREADS), sgc_extra_lds("CORE"), st, IN, CV, am, L, lib, perm, FWD, OUT, counts, matched, dbg)
     if (pass == 2) {    // -x: the one exact-only pass over the runs k_count_slices left in buf0
         if (l20) KC_LAUNCH(true, true, 20, ra, ca, (uint64_t *)nullptr, ra); else KC_LAUNCH(true, true, 0, ra, ca, (uint64_t *)nullptr, ra);
     } else if (pass == 0) { // pass A: the runs k_count_slices left in buf0; forwards go to buf1 run by run, then to buf2 as pass B's runs

@@ -3,8 +3,61 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "sgc_format.h"
+
+// -DSGC_STAMPS=1 builds, dbg 1048576: every workgroup leaves one row — where it ran (XCD; HW_ID: wave / SIMD / CU / SE) and when
+// (the constant 100 MHz clock) — in a buffer of its kernel, which sgc_*_timeline_dump() prints after the pass ("TL" lines:
+// tools/wg_timeline.py draws the timeline of a kernel from them).  (A printf from the kernel itself stretches the lifetimes.)
+#ifndef SGC_STAMPS
+#define SGC_STAMPS 0
+#endif
+struct sgc_tl_row { unsigned long long begin, end, cycles; uint32_t xcc, hw, extra, used; };     // cycles: s_memtime ticks over the lifetime
+#define SGC_TL_MAXWG 2048u
+__device__ __forceinline__ uint32_t sgc_xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20); }      // hwreg(HW_REG_XCC_ID, 0, 4)
+__device__ __forceinline__ uint32_t sgc_hw_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 4); }       // hwreg(HW_REG_HW_ID)
+#if SGC_STAMPS
+#define SGC_TIMELINE_BEGIN(dbg)                                                                                                  \
+    const unsigned long long tl_begin_ = (SGC_STAMPS && ((dbg) & 1048576u)) ? __builtin_amdgcn_s_memrealtime() : 0ull,             \
+                             tl_cyc_ = (SGC_STAMPS && ((dbg) & 1048576u)) ? __builtin_amdgcn_s_memtime() : 0ull
+#define SGC_TIMELINE_END(dbg, buf, extra_)                                                                                       \
+    if (SGC_STAMPS && ((dbg) & 1048576u) && threadIdx.x == 0 && blockIdx.x < SGC_TL_MAXWG) {                                      \
+        sgc_tl_row row_;                                                                                                          \
+        row_.begin = tl_begin_; row_.end = __builtin_amdgcn_s_memrealtime(); row_.xcc = sgc_xcc_id(); row_.hw = sgc_hw_id();     \
+        row_.extra = (uint32_t)(extra_); row_.used = 1; row_.cycles = __builtin_amdgcn_s_memtime() - tl_cyc_;                                                                           \
+        buf[blockIdx.x] = row_;                                                                                                   \
+    }
+#else
+#define SGC_TIMELINE_BEGIN(dbg)
+#define SGC_TIMELINE_END(dbg, buf, extra_)
+#endif
+// SGC_EXTRA_LDS_K1 / _K2 / _CORE (environment, -DSGC_STAMPS=1 builds only): dynamic LDS added to the launches of that kernel, to
+// hold it to one workgroup per CU — the occupancy experiments of DESIGN.md
+static inline unsigned sgc_extra_lds(const char *which) {
+#if SGC_STAMPS
+    char name[64];
+    snprintf(name, sizeof name, "SGC_EXTRA_LDS_%s", which);
+    const char *v = getenv(name);
+    return v ? (unsigned)atoi(v) : 0u;
+#else
+    (void)which;
+    return 0u;
+#endif
+}
+// host side of a .hip file that owns such buffers
+#define SGC_TIMELINE_DUMP(buf, name)                                                                                             \
+    do {                                                                                                                          \
+        static sgc_tl_row h_[SGC_TL_MAXWG];                                                                                       \
+        (void)hipDeviceSynchronize();                                                                                             \
+        if (hipMemcpyFromSymbol(h_, HIP_SYMBOL(buf), sizeof h_) != hipSuccess) break;                                             \
+        for (uint32_t i_ = 0; i_ < SGC_TL_MAXWG; i_++)                                                                            \
+            if (h_[i_].used) printf("TL %s wg %u xcc %u hw %x begin %llu end %llu extra %u cycles %llu\n", name, i_, h_[i_].xcc, h_[i_].hw, h_[i_].begin, h_[i_].end, h_[i_].extra, h_[i_].cycles); \
+        memset(h_, 0, sizeof h_);                                                                                                 \
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(buf), h_, sizeof h_);                                                                  \
+    } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // bucketised open addressing: one 16-byte load reads both slots of a bucket

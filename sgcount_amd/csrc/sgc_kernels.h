@@ -64,11 +64,16 @@ void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_
 // sub_bits: with core-hashed slices, log2 (1..2) of core pass A's partitions per slice, tagged into the clean records; else 0
 void sgc_launch_part_k1(hipStream_t st, unsigned long long *err /* the sample's error word (SGC_CHECK builds) */, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib, uint32_t sub_bits,
                         const sgc_part_geometry &g, uint64_t *pool, uint32_t *desc,
-                        int slice_rec /* what the slice blocks hold: 0 = 8-byte records, 1 = six-byte (direct runs, core-hashed slices, 2 (L + 2) + 2 <= 48), 2 = five-byte (2 (L + 2) - slice bits <= 40) */);
+                        int slice_rec /* what the slice blocks hold: 0 = 8-byte records, 1 = six-byte (direct runs, core-hashed slices, 2 (L + 2) + 2 <= 48), 2 = five-byte (2 (L + 2) - slice bits <= 40) */,
+                        uint32_t dbg,
+                        uint32_t *slice_tot /* NULL, or SGC_SLICE_TOT words, all zero: the blocks of every slice are added up there for the
+                                               balanced shares of k_count_slices */);
+#define SGC_SLICE_TOT 256u
 struct sgc_runs;       // sgc_runs.h
 // runs != NULL: the leftovers (misses, generic blocks) are laid out as the runs of core pass A by the kernel's epilogue
 uint32_t sgc_part_k2_grid(const sgc_part_geometry &g);
 uint32_t sgc_part_k2_shares(const sgc_part_geometry &g);     // workgroups per slice
+uint32_t sgc_part_k2_direct_cols(const sgc_part_geometry &g, bool balanced);
 void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_part_geometry &g,
                         uint64_t *pool, uint32_t *desc, uint32_t *counts, unsigned long long *matched, uint32_t dbg,
                         const sgc_runs *runs, const uint64_t *cuckoo /* two-choice image of the slices, or NULL */,
@@ -76,8 +81,11 @@ void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, c
                         uint32_t *mcur /* its bump allocator, zeroed */,
                         bool direct_runs /* with mrun and tagged sub-partitions: the misses go straight to per-partition runs that are
                                             pass A's input (mrun: pool records << runs->sub_bits, inside runs->recs' allocation; the run
-                                            matrices have shares + grid columns) */,
-                        int slice_rec /* as given to sgc_launch_part_k1 */);
+                                            matrices have shares + grid columns, or 2 x grid with slice_tot) */,
+                        int slice_rec /* as given to sgc_launch_part_k1 */,
+                        const uint32_t *slice_tot /* what k_partition added up (direct runs only), or NULL = static shares: the same
+                                                     number of workgroups for every slice */,
+                        uint32_t *slice_tot_next /* with slice_tot: SGC_SLICE_TOT words the kernel zeroes for the next pass */);
 void sgc_launch_part_k3(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm,
                         const sgc_bloom_view &bloom_lib, const sgc_bloom_view &bloom_perm, const sgc_part_geometry &g,
                         const uint64_t *pool, const uint32_t *desc, uint32_t *seg_cnt, uint32_t *gids, uint32_t dbg);
@@ -103,6 +111,9 @@ void sgc_launch_core(hipStream_t st, int pass, uint32_t L, const sgc_table_view 
                      unsigned long long *matched, uint32_t dbg);
 
 void sgc_core_print_occupancy();
+// -DSGC_STAMPS=1 builds: print and clear the workgroup timelines of the last pass (dbg 1048576; sgc_device.h)
+void sgc_part_timeline_dump();
+void sgc_core_timeline_dump();
 
 // ---- device-side build of the single-mismatch table, its Bloom filter and the ambiguity masks (sgc_build.hip)
 size_t sgc_device_build_scratch_bytes(uint32_t n, uint32_t L);

@@ -129,6 +129,15 @@ __device__ __forceinline__ uint32_t part_of(uint64_t &rec, uint64_t kmask, uint3
 #endif
 __device__ __forceinline__ uint32_t part_rot(uint32_t b) { return PART_ROT ? ((b * 2654435761u) >> 29) << 6 : 0u; }
 
+#if SGC_STAMPS
+static __device__ sgc_tl_row tl_k1[SGC_TL_MAXWG], tl_k2loop[SGC_TL_MAXWG], tl_k2[SGC_TL_MAXWG];
+#endif
+void sgc_part_timeline_dump() {
+#if SGC_STAMPS
+    SGC_TIMELINE_DUMP(tl_k1, "K1"); SGC_TIMELINE_DUMP(tl_k2loop, "K2loop"); SGC_TIMELINE_DUMP(tl_k2, "K2");
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------ K1
 template <int MODE>
 __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__restrict__ recs, uint64_t n, uint64_t per_wg,
@@ -136,8 +145,10 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
                                                    uint32_t log2_slice, uint32_t core_cl, uint32_t sub_bits, uint64_t *__restrict__ pool,
                                                    uint32_t *__restrict__ desc, uint32_t *__restrict__ tail,
                                                    uint32_t tail_words, uint32_t *__restrict__ wcnt,
-                                                   uint32_t *__restrict__ wlist, unsigned long long *__restrict__ err) {
+                                                   uint32_t *__restrict__ wlist, unsigned long long *__restrict__ err, uint32_t dbg,
+                                                   uint32_t *__restrict__ slice_tot) {
     constexpr bool p6 = MODE == 2, p5 = MODE == 3;
+    SGC_TIMELINE_BEGIN(dbg);
     __shared__ uint64_t stage[PART_TILE];
     __shared__ uint8_t stage_p[PART_TILE];               // partition of every staged record
     __shared__ uint32_t cnt[PART_ARR], start[PART_ARR], blk[PART_ARR], fill[PART_ARR];
@@ -267,8 +278,12 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
     // scratch counters behind the descriptors (no separate memset on the stream)
     for (uint32_t i = next_free + t; i < blocks_per_wg; i += K1_THREADS) desc[block0 + i] = 0;
     if (t < PART_ARR) wcnt[blockIdx.x * PART_ARR + t] = nblk[t];
+    // blocks per slice over all workgroups: k_count_slices cuts equal shares of the whole from them (zeroed by the k_count_slices
+    // of the pass before)
+    if (slice_tot && t < P && nblk[t]) atomicAdd(&slice_tot[t], nblk[t]);
     if (blockIdx.x == 0)
         for (uint32_t i = t; i < tail_words; i += K1_THREADS) tail[i] = 0;
+    SGC_TIMELINE_END(dbg, tl_k1, next_free);
 }
 
 // ------------------------------------------------------------------------------------------------ K2
@@ -290,6 +305,24 @@ __device__ __forceinline__ uint64_t k2_record(const uint64_t *__restrict__ pool,
     const uint32_t lo = reinterpret_cast<const uint32_t *>(bb)[j];
     const uint32_t hi = REC == 2 ? (uint32_t)reinterpret_cast<const uint8_t *>(bb + P6_HI_OFF)[j] : (uint32_t)reinterpret_cast<const uint16_t *>(bb + P6_HI_OFF)[j];
     return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+// balanced shares (k_count_slices): a sequence of T blocks dealt to n workgroups in order, T / n blocks each and one more for the
+// first T % n — so the workgroups with nothing to do (T < n) come last, and between the first and the last workgroup of a slice
+// every workgroup holds blocks of it.  k2_share_lo: first block of workgroup j (j <= n); k2_owner: the workgroup that holds block x (< T)
+__device__ __forceinline__ uint32_t k2_share_lo(uint32_t j, uint32_t n, uint32_t T) {
+    const uint32_t base = T / n, rem = T % n;
+    return j * base + (j < rem ? j : rem);
+}
+__device__ __forceinline__ uint32_t k2_owner(uint32_t x, uint32_t n, uint32_t T) {
+    const uint32_t base = T / n, rem = T % n, big = rem * (base + 1u);
+    return x < big ? x / (base + 1u) : rem + (x - big) / base;        // (x >= big implies base > 0: big = T when base = 0)
+}
+
+// workgroups whose shares hold blocks of slice p (spre: first block of every slice in the sequence)
+__device__ __forceinline__ uint32_t k2_slice_wgs(const uint32_t *spre, uint32_t p, uint32_t n, uint32_t T) {
+    const uint32_t b0 = spre[p], b1 = spre[p + 1u];
+    return b1 > b0 ? k2_owner(b1 - 1u, n, T) - k2_owner(b0, n, T) + 1u : 0u;
 }
 
 // CUCKOO: the slice is staged from its two-choice image (`cuck`, sgc_format.h sgc_cuckoo_alt): both candidate slots are
@@ -318,8 +351,10 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                                                              sgc_table_view lib, uint32_t *__restrict__ counts,
                                                              unsigned long long *__restrict__ matched, uint32_t dbg,
                                                              const sgc_runs ep, const uint64_t *__restrict__ cuck,
-                                                             uint64_t *__restrict__ mrun, uint32_t *__restrict__ mcur) {
+                                                             uint64_t *__restrict__ mrun, uint32_t *__restrict__ mcur,
+                                                             const uint32_t *__restrict__ slice_tot, uint32_t *__restrict__ slice_tot_next) {
     constexpr uint32_t S = 1u << LOG2_SLICE;
+    SGC_TIMELINE_BEGIN(dbg);
     constexpr bool P6 = REC != 0;                            // packed slice blocks: no slot tag in the record, the key is hashed here
     const uint32_t L = LT ? (uint32_t)LT : L_arg;
     // (LT: the launcher checked that the arguments say the same)
@@ -337,7 +372,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     __shared__ uint32_t hn[RUN_MAXP], rcur[RUN_MAXP], rbase, preg[K2_THREADS];   // epilogue: leftovers by partition of core pass A
     __shared__ uint32_t wmiss, mbase;                                              // DENSE: misses so far, start of the stretch in mrun
     __shared__ uint32_t wmiss4[4];                                                 // DIRECT: misses so far, by sub-partition
-    const uint32_t t = threadIdx.x, p = blockIdx.x / G, g = blockIdx.x % G;
+    const uint32_t t = threadIdx.x;
     const uint32_t h = __builtin_amdgcn_readfirstlane(t / PART_BLOCK), jl = t % PART_BLOCK;
     const bool count_sub = ep.recs != nullptr && ep.sub_bits != 0xFFu;      // wave-uniform
     const uint32_t slice = (!LT && lib.log2_slice < (uint32_t)LOG2_SLICE) ? (1u << lib.log2_slice) : S;   // small libraries
@@ -346,6 +381,60 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     const uint64_t *gslots = CUCKOO ? cuck : lib.slots;                // where the slice's slots (key << gid_bits | gid) live
     const uint32_t ls = (!LT && lib.log2_slice < (uint32_t)LOG2_SLICE) ? lib.log2_slice : (uint32_t)LOG2_SLICE;   // log2 slots per slice
     const uint64_t *tab1 = reinterpret_cast<const uint64_t *>(tab);                                       // the same keys, slot by slot
+    for (uint32_t i = t; i < RUN_MAXP; i += K2_THREADS) hn[i] = 0;
+    if (t < 2 * K2_U * BPS) miss_cnt[t / (K2_U * BPS)][t % (K2_U * BPS)] = 0;
+    // diagnostic stamps (SGC_STAMPS && (dbg & 512)): cycle counts of the phases of a few workgroups, printed at the end
+    unsigned long long ts0 = 0, ts_scan = 0, ts_loop = 0;
+    uint32_t n_groups_dbg = 0;
+    if (SGC_STAMPS && (dbg & 512)) ts0 = __builtin_amdgcn_s_memtime();
+    // Which blocks of which slice.  K1 workgroup w handed slice p wcnt[w][p] blocks, listed in wlist[w][p][]: in that order
+    // (w major) the slice's blocks form one sequence.
+    //   static (slice_tot == nullptr): workgroup (p, g) = (blockIdx / G, blockIdx % G) takes the g-th of G equal shares of
+    //     slice p — fine while the slices hold the same number of blocks;
+    //   balanced (DIRECT, with k_partition's per-slice block totals): the sequences of all slices, one after the other, are
+    //     ONE sequence of which every workgroup takes an equal share — a workgroup whose share crosses from one slice into
+    //     the next works through two (rarely more) SEGMENTS, each with its own staging of the slice, flush of the counters
+    //     and column of the run matrices.  Guides are not read equally often (a few hundred hot guides fall unevenly into 64
+    //     slices: +-15 % of blocks per slice on the bench workload, any factor on a sample that a few guides dominate), and
+    //     the kernel ends with its slowest workgroup.
+    const bool balanced = DIRECT && slice_tot != nullptr;                // wave-uniform (kernel argument)
+    const uint32_t n_slices = 1u << (lib.log2_slots - lib.log2_slice), NW = gridDim.x;
+    __shared__ uint32_t spre[PART_MAXP + 1];                             // balanced: first block of every slice in the global sequence
+    uint32_t gx = 0, gx_hi = 0, T_all = 0;
+    if (balanced) {
+        const uint32_t v = t < n_slices ? slice_tot[t] : 0u;
+        const uint32_t e = wg_scan_1024(v, wtmp, &T_all);
+        if (t <= n_slices) spre[t] = e;                                  // spre[n_slices] = T_all
+        if (blockIdx.x == 0 && t < PART_ARR) slice_tot_next[t] = 0;      // the next pass's k_partition adds its totals up there
+        __syncthreads();
+        gx = k2_share_lo(blockIdx.x, NW, T_all);
+        gx_hi = k2_share_lo(blockIdx.x + 1u, NW, T_all);
+        // A row of the run matrices (a partition of core pass A inside slice p) holds, without gaps — the consumer walks over
+        // empty columns one by one —: the G_p workgroups whose shares meet slice p (k2_slice_wgs), then every workgroup's part
+        // of the generic blocks, then the G - G_p columns nobody fills: workgroup p clears those.
+        if (blockIdx.x < n_slices) {
+            const uint32_t used = k2_slice_wgs(spre, blockIdx.x, NW, T_all);
+            const uint32_t rows = 1u << sub_bits, width = G - used;
+            for (uint32_t i = t; i < rows * width; i += K2_THREADS)
+                ep.cnt[(size_t)((blockIdx.x << sub_bits) + i / width) * ep.W + used + NW + i % width] = 0;
+        }
+    }
+    uint64_t local = 0;                                                    // reads this lane's slots counted (all segments)
+    bool first_seg = true;
+    uint32_t p = 0, g = 0, s_lo = 0, s_hi = 0, run0 = 0, stretch = 0;
+    for (;;) {
+    if (balanced) {
+        if (gx >= gx_hi) break;
+        p = find_extent<7>(spre, n_slices, gx);                                   // last slice that starts at or before block gx: the one that holds it
+        s_lo = gx - spre[p];
+        s_hi = (gx_hi < spre[p + 1] ? gx_hi : spre[p + 1]) - spre[p];
+        g = blockIdx.x - k2_owner(spre[p], NW, T_all);
+        gx = spre[p] + s_hi;
+    } else {
+        if (!first_seg) break;
+        p = blockIdx.x / G; g = blockIdx.x % G;
+    }
+    __syncthreads();                                                     // the previous segment is done with tab[], cnt[], pre[], wmiss4[]
     const ulonglong2 *gtab = reinterpret_cast<const ulonglong2 *>(gslots) + (uint64_t)p * (slice / 2);
     for (uint32_t i = t; i < S / 2; i += K2_THREADS) {      // bare keys in LDS (a key is < 2^60, so SGC_EMPTY stays distinct)
         ulonglong2 v = i < slice / 2 ? gtab[i] : make_ulonglong2(SGC_EMPTY, SGC_EMPTY);
@@ -354,21 +443,16 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
         tab[i] = v;
     }
     for (uint32_t i = t; i < S; i += K2_THREADS) cnt[i] = 0;
-    for (uint32_t i = t; i < RUN_MAXP; i += K2_THREADS) hn[i] = 0;
-    if (t < 2 * K2_U * BPS) miss_cnt[t / (K2_U * BPS)][t % (K2_U * BPS)] = 0;
-    // diagnostic stamps (SGC_STAMPS && (dbg & 512)): cycle counts of the phases of a few workgroups, printed at the end
-    unsigned long long ts0 = 0, ts_scan = 0, ts_loop = 0;
-    uint32_t n_groups_dbg = 0;
-    if (SGC_STAMPS && (dbg & 512)) ts0 = __builtin_amdgcn_s_memtime();
-    // K1 workgroup w handed this partition wcnt[w][p] blocks, listed in wlist[w][p][]: in that order (w major) the
-    // partition's blocks form one sequence, of which this workgroup takes the g-th of G equal shares — no scan of
-    // the descriptors, and shares that differ by at most one block.
-    uint32_t Bp;
-    pre[t] = wg_scan_1024(t < k1_wgs ? wcnt[t * PART_ARR + p] : 0u, wtmp, &Bp);
-    __syncthreads();
-    const uint32_t s_lo = (uint32_t)((uint64_t)Bp * g / G), s_hi = (uint32_t)((uint64_t)Bp * (g + 1) / G);
-    uint32_t run0 = 0;
-    const uint32_t stretch = (s_hi - s_lo) * PART_BLOCK;           // no run can lack room: as long as all blocks of the share
+    {
+        uint32_t Bp;
+        pre[t] = wg_scan_1024(t < k1_wgs ? wcnt[t * PART_ARR + p] : 0u, wtmp, &Bp);
+        __syncthreads();
+        if (!balanced) { s_lo = (uint32_t)((uint64_t)Bp * g / G); s_hi = (uint32_t)((uint64_t)Bp * (g + 1) / G); }
+        else if (!SGC_BOUND(s_hi <= Bp, reinterpret_cast<unsigned long long *>(matched) + 3, 12)) s_hi = s_lo;      // k_partition's totals and its lists disagree
+    }
+    first_seg = false;
+    run0 = 0;
+    stretch = (s_hi - s_lo) * PART_BLOCK;                         // no run can lack room: as long as all blocks of the share
     if (DENSE) {
         if (t < 4) wmiss4[t] = 0;
         if (t == 0) { wmiss = 0; mbase = s_hi > s_lo ? atomicAdd(mcur, DIRECT ? stretch << sub_bits : stretch) : 0u; }
@@ -506,7 +590,6 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     if ((SGC_STAMPS && (dbg & 512)) && t == 0 && (blockIdx.x % 97) == 0)
         printf("K2 wg %u slice %u: scan %llu loop %llu cycles, %u groups\n", blockIdx.x, p, ts_scan, ts_loop, n_groups_dbg);
     // flush the slot counters: one atomic per occupied slot
-    uint64_t local = 0;
     for (uint32_t i = t; i < slice; i += K2_THREADS) {
         const uint32_t c = SGC_DBG(dbg, 524288u) ? 0u : cnt[i];       // dbg 524288: timing-only, no flush
         if (c) {
@@ -514,6 +597,15 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             local += c;
         }
     }
+    if (DIRECT && t < (1u << sub_bits) && ep.recs) {
+        // the direct runs: row (p << sub_bits | sub) of the run matrices belongs to this slice alone, so the workgroups that work
+        // on it take columns 0 .. of it (the generic shares follow from column G): no empty columns for the consumer to walk over
+        const uint32_t q = (p << sub_bits) | t, c = wmiss4[t];
+        ep.cnt[(size_t)q * ep.W + g] = c;
+        ep.off[(size_t)q * ep.W + g] = (uint32_t)(mrun - ep.recs) + run0 + t * stretch;
+        if (c) atomicAdd(&ep.tot[q], c);
+    }
+    }       // segments
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
     __shared__ unsigned long long wsum;
     if (t == 0) wsum = 0;
@@ -521,6 +613,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     if ((t & 63) == 0 && local) atomicAdd(&wsum, (unsigned long long)local);
     __syncthreads();
     if (t == 0 && wsum) atomicAdd(matched, wsum);
+    SGC_TIMELINE_END(dbg, tl_k2loop, s_hi - s_lo);
     if (!ep.recs || SGC_DBG(dbg, 262144u)) return;
     // Epilogue (sgc_runs.h): what this workgroup could not settle — the misses it compacted to the fronts of its blocks —
     // and its share of the generic partition's blocks (records with an 'N' or a dead window: nothing to probe here) go to
@@ -613,16 +706,13 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             }
         }
         __syncthreads();
-        if (sweep == 0) run_reserve(ep, DIRECT ? G + blockIdx.x : blockIdx.x, hn, rcur, wtmp, &rbase);
+        // this workgroup's column in row t (thread t): behind the direct runs of the row's slice
+        if (sweep == 0)
+            run_reserve(ep, !DIRECT ? blockIdx.x : !balanced ? G + blockIdx.x :
+                            (t < (n_slices << sub_bits) ? k2_slice_wgs(spre, t >> sub_bits, NW, T_all) : 0u) + blockIdx.x,
+                        hn, rcur, wtmp, &rbase);
     }
-    if (DIRECT && t < (1u << sub_bits)) {
-        // the direct runs: row (p << sub_bits | sub) of the run matrices belongs to this slice alone, so its G workgroups take
-        // columns 0 .. G - 1 of it (the generic shares follow from column G): no empty columns for the consumer to walk over
-        const uint32_t q = (p << sub_bits) | t, c = wmiss4[t];
-        ep.cnt[(size_t)q * ep.W + g] = c;
-        ep.off[(size_t)q * ep.W + g] = (uint32_t)(mrun - ep.recs) + run0 + t * stretch;
-        if (c) atomicAdd(&ep.tot[q], c);
-    }
+    SGC_TIMELINE_END(dbg, tl_k2, s_hi - s_lo);
 }
 
 // ------------------------------------------------------------------------------------------------ K3
@@ -880,12 +970,12 @@ void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_
 }
 
 void sgc_launch_part_k1(hipStream_t st, unsigned long long *err, const uint64_t *recs, uint64_t n, uint32_t L, const sgc_table_view &lib, uint32_t sub_bits,
-                        const sgc_part_geometry &g, uint64_t *pool, uint32_t *desc, int slice_rec) {
+                        const sgc_part_geometry &g, uint64_t *pool, uint32_t *desc, int slice_rec, uint32_t dbg, uint32_t *slice_tot) {
     const bool core_hashed = lib.core_cl != 0 && lib.log2_slice < lib.log2_slots;
 #define K1_LAUNCH(MODE)                                                                                                            \
-    hipLaunchKernelGGL((k_partition<MODE>), dim3(g.k1_wgs), dim3(K1_THREADS), 0, st, recs, n, g.per_wg, g.blocks_per_wg, L,          \
+    hipLaunchKernelGGL((k_partition<MODE>), dim3(g.k1_wgs), dim3(K1_THREADS), sgc_extra_lds("K1"), st, recs, n, g.per_wg, g.blocks_per_wg, L,          \
                        lib.log2_slots, lib.log2_slice, lib.core_cl, sub_bits, pool, desc, (uint32_t *)((char *)desc + g.desc_tail_off), \
-                       SGC_DESC_TAIL / 4, (uint32_t *)((char *)desc + g.wcnt_off), (uint32_t *)((char *)desc + g.wlist_off), err)
+                       SGC_DESC_TAIL / 4, (uint32_t *)((char *)desc + g.wcnt_off), (uint32_t *)((char *)desc + g.wlist_off), err, dbg, slice_tot)
     if (slice_rec == 2 && core_hashed) K1_LAUNCH(3);
     else if (slice_rec == 1 && core_hashed) K1_LAUNCH(2);
     else if (core_hashed) K1_LAUNCH(1);
@@ -897,24 +987,34 @@ void sgc_launch_part_k1(hipStream_t st, unsigned long long *err, const uint64_t 
 static uint32_t k2_shares(const sgc_part_geometry &g) { return g.partitions >= 512 ? 1 : 512 / g.partitions; }
 uint32_t sgc_part_k2_grid(const sgc_part_geometry &g) { return g.partitions * k2_shares(g); }
 uint32_t sgc_part_k2_shares(const sgc_part_geometry &g) { return k2_shares(g); }
+// columns of the run matrices for the direct runs
+uint32_t sgc_part_k2_direct_cols(const sgc_part_geometry &g, bool balanced) {
+    if (!balanced) return k2_shares(g);
+    return g.partitions * k2_shares(g);          // any workgroup may meet any slice
+}
 
 void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_part_geometry &g,
                         uint64_t *pool, uint32_t *desc, uint32_t *counts, unsigned long long *matched, uint32_t dbg,
-                        const sgc_runs *runs, const uint64_t *cuckoo, uint64_t *mrun, uint32_t *mcur, bool direct_runs, int slice_rec) {
-    const uint32_t G = k2_shares(g);
+                        const sgc_runs *runs, const uint64_t *cuckoo, uint64_t *mrun, uint32_t *mcur, bool direct_runs, int slice_rec,
+                        const uint32_t *slice_tot, uint32_t *slice_tot_next) {
+    const uint32_t grid = g.partitions * k2_shares(g);
+    // balanced shares (slice_tot: k_partition's blocks per slice; direct runs only): any workgroup may work on any slice, so the run
+    // matrices keep `grid` columns for the direct runs; static shares: the k2_shares(g) workgroups of a slice
+    if (!(runs && mrun && direct_runs && runs->sub_bits != 0xFFu)) slice_tot = nullptr;
+    const uint32_t G = slice_tot ? sgc_part_k2_direct_cols(g, true) : k2_shares(g);
     sgc_runs none{};
     const uint32_t *wcnt = (const uint32_t *)((const char *)desc + g.wcnt_off), *wlist = (const uint32_t *)((const char *)desc + g.wlist_off);
     const bool dense = runs && mrun;
     const bool direct = dense && direct_runs && runs->sub_bits != 0xFFu;
 #define K2_LAUNCH(CK, DN, DR, REC)                                                                                                     \
-    hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE, CK, DN, DR, REC>), dim3(g.partitions * G), dim3(K2_THREADS), 0, st, pool, desc, wcnt, wlist, \
-                       g.k1_wgs, g.blocks_per_wg, G, L, lib, counts, matched, dbg, runs ? *runs : none, cuckoo, mrun, mcur)
+    hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE, CK, DN, DR, REC>), dim3(grid), dim3(K2_THREADS), sgc_extra_lds("K2"), st, pool, desc, wcnt, wlist, \
+                       g.k1_wgs, g.blocks_per_wg, G, L, lib, counts, matched, dbg, runs ? *runs : none, cuckoo, mrun, mcur, slice_tot, slice_tot_next)
     const int rec = direct ? slice_rec : 0;          // 0 = 8-byte, 1 = six-byte, 2 = five-byte slice blocks
     const bool l20 = L == 20 && rec == 2 && cuckoo && lib.core_cl == 9 && lib.log2_slice == SGC_LDS_LOG2_SLICE &&
                      lib.log2_slots == SGC_LDS_LOG2_SLICE + 6u && runs->sub_bits == 2;
     if (l20)
-        hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE, true, true, true, 2, 20>), dim3(g.partitions * G), dim3(K2_THREADS), 0, st, pool, desc, wcnt, wlist,
-                           g.k1_wgs, g.blocks_per_wg, G, L, lib, counts, matched, dbg, *runs, cuckoo, mrun, mcur);
+        hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE, true, true, true, 2, 20>), dim3(grid), dim3(K2_THREADS), sgc_extra_lds("K2"), st, pool, desc, wcnt, wlist,
+                           g.k1_wgs, g.blocks_per_wg, G, L, lib, counts, matched, dbg, *runs, cuckoo, mrun, mcur, slice_tot, slice_tot_next);
     else if (cuckoo) { if (rec == 2) K2_LAUNCH(true, true, true, 2); else if (rec == 1) K2_LAUNCH(true, true, true, 1); else if (direct) K2_LAUNCH(true, true, true, 0); else if (dense) K2_LAUNCH(true, true, false, 0); else K2_LAUNCH(true, false, false, 0); }
     else { if (rec == 2) K2_LAUNCH(false, true, true, 2); else if (rec == 1) K2_LAUNCH(false, true, true, 1); else if (direct) K2_LAUNCH(false, true, true, 0); else if (dense) K2_LAUNCH(false, true, false, 0); else K2_LAUNCH(false, false, false, 0); }
 #undef K2_LAUNCH

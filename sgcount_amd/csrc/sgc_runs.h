@@ -41,7 +41,8 @@ __device__ __forceinline__ uint32_t run_part(const sgc_runs &r, uint64_t rec) {
 
 // Producer epilogue, part 1 (all threads of a 1024-lane workgroup; hn[p] = this workgroup's records per partition,
 // complete and visible): takes the region, publishes the matrices' column w, leaves cur[p] = index in r.recs where
-// the next record of partition p goes.  hn, cur: LDS arrays of RUN_MAXP entries; wtmp: LDS scratch of 17 words.
+// the next record of partition p goes.  hn, cur: LDS arrays of RUN_MAXP entries; wtmp: LDS scratch of 17 words.  w may differ
+// from thread to thread: thread t publishes row t.
 __device__ __forceinline__ void run_reserve(const sgc_runs &r, uint32_t w, const uint32_t *hn, uint32_t *cur, uint32_t *wtmp,
                                             uint32_t *base_slot /* one LDS word */) {
     const uint32_t t = threadIdx.x, P = 1u << r.log2_p;

@@ -61,12 +61,15 @@ SGC_HD void sgs_make_spec(uint64_t seed, uint64_t i, uint32_t n_guides, uint32_t
     const uint32_t u = (uint32_t)(d0 % 100);
     sp.cls = u < 85 ? 0 : u < 90 ? 1 : u < 91 ? 2 : u < 93 ? 3 : u < 95 ? 4 : u < 99 ? 5 : 6;
     sp.gid = n_guides ? sgs_pick_guide(d1, n_guides) : 0;
+    // mode bits 8..14 (SGS_MODE_DOMINANT(pct)): that percentage of the reads takes ONE guide (index 7 % n) instead — a sample a single
+    // guide dominates, the worst case for anything that shares the reads out by guide
+    if (n_guides && ((mode >> 8) & 127u) && (uint32_t)((d1 >> 40) % 100) < ((mode >> 8) & 127u)) sp.gid = 7u % n_guides;
     sp.pos = (uint32_t)(d2 % L);
     sp.alt = 1 + (uint32_t)((d2 >> 32) % 3);
     sp.junk = d3;
     sp.lead = d4;
     uint32_t P = SGS_P0;
-    if (mode == 1) {  // stagger: 28..32 with weights 5/10/70/10/5
+    if ((mode & 255u) == 1) {  // stagger: 28..32 with weights 5/10/70/10/5
         const uint32_t v = (uint32_t)((d0 >> 32) % 100);
         P = v < 5 ? 28 : v < 15 ? 29 : v < 85 ? 30 : v < 95 ? 31 : 32;
     }

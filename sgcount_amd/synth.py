@@ -10,6 +10,11 @@ import numpy as np
 from . import _ffi, build as _build
 
 MODE_FIXED, MODE_STAGGER = 0, 1
+
+
+def mode_dominant(pct):
+    """| into a mode: pct percent of the reads draw ONE guide (include/sgcount_synth.h SGS_MODE_DOMINANT)"""
+    return (int(pct) & 127) << 8
 READ_LEN, PREFIX_LEN = 150, 30
 LIB_SEED, READS_SEED = 0x5EED0001, 0x5EED0002
 

@@ -84,7 +84,7 @@ def test_synthetic_workload_vs_oracle_2m(env, exact):
 
 @pytest.mark.parametrize("exact", [False, True])
 def test_every_fallback_mode_gives_the_same_table(env, exact):
-    """The shipped pass is a stack of results-preserving choices (five-byte > six-byte slice blocks > direct miss runs > dense runs >
+    """The shipped pass is a stack of results-preserving choices (balanced shares of the slice blocks, five-byte > six-byte slice blocks > direct miss runs > dense runs >
     sub-partition tag > two-choice image > core-hashed slices); each one has a fallback that libraries of other shapes take
     (L >= 22, slices that do not follow the core hash, ...).  Every rung of that ladder must count the same table — the
     oracle's — on the same 1M reads."""
@@ -92,7 +92,7 @@ def test_every_fallback_mode_gives_the_same_table(env, exact):
     n, ng = 1_000_000, 20_000
     lib_text = None
     want = None
-    ladder = [({}, {}), ({}, {"five_byte": 0}), ({}, {"five_byte": 0, "six_byte": 0}), ({}, {"direct": 0}), ({}, {"dense": 0}), ({}, {"tag_sub": 0}), ({}, {"cuckoo": 0}),
+    ladder = [({}, {}), ({}, {"five_byte": 0}), ({}, {"five_byte": 0, "six_byte": 0}), ({}, {"balanced": 0}), ({}, {"direct": 0}), ({}, {"dense": 0}), ({}, {"tag_sub": 0}), ({}, {"cuckoo": 0}),
               ({}, {"direct": 0, "cuckoo": 0, "tag_sub": 0}), ({"align_slices": 0}, {}), ({"align_slices": 0}, {"dense": 0, "cuckoo": 0}),
               ({"rest_filter": 0}, {}), ({}, {"variant": 3}), ({}, {"variant": 1})]
     for lib_opts, opts in ladder:
@@ -109,6 +109,32 @@ def test_every_fallback_mode_gives_the_same_table(env, exact):
                 ctr.feed_text(synth.fastq_host(wl.lib_seqs, first, 500_000))
             want = (ctr.table(), ctr.total_reads(), ctr.matched_reads())
         assert (counts.tolist(), total, matched) == want, (lib_opts, opts)
+        wl.close()
+
+
+@pytest.mark.parametrize("pct", [10, 60])
+def test_sample_dominated_by_one_guide_vs_oracle(env, pct):
+    """pct percent of the reads draw ONE guide (synth.mode_dominant): its slice holds most of the slice blocks, so with balanced
+    shares most workgroups of k_count_slices work on that one slice (and some on two or three slices: segments), with static
+    shares eight of them do.  Both must count the oracle's table."""
+    torch, S, synth, workload = env
+    n, ng = 1_000_000, 20_000
+    mode = synth.MODE_FIXED | synth.mode_dominant(pct)
+    want = None
+    for opts in ({}, {"balanced": 0}):
+        wl = workload.DeviceWorkload(n, ng, 20, one_mismatch=True, gen_chunk=500_000, mode=mode)
+        for k, v in opts.items():
+            wl.dl.set_option(k, v)
+        wl.step()
+        counts, total, matched = wl.result()
+        if want is None:
+            lib = O.Library(synth.library_fasta(wl.lib_seqs))
+            ctr = O.Counter(lib, O.Permuter(lib), False, 30, 20, True)
+            for first in range(0, n, 500_000):
+                ctr.feed_text(synth.fastq_host(wl.lib_seqs, first, 500_000, mode=mode))
+            want = (ctr.table(), ctr.total_reads(), ctr.matched_reads())
+            assert max(want[0]) >= pct * n * 0.85 // 100            # the dominant guide really dominates
+        assert (counts.tolist(), total, matched) == want, opts
         wl.close()
 
 
@@ -383,8 +409,9 @@ def test_extreme_skew(env):
     big = big[torch.randperm(big.numel(), device="cuda")]          # interleave the three kinds
     dl = library.device(True)
     dl.set_stream(torch.cuda.current_stream().cuda_stream)
-    for variant in (4, 3):
+    for variant, balanced in ((4, 1), (4, 0), (3, 1)):
         dl.set_option("variant", variant)
+        dl.set_option("balanced", balanced)
         smp = C.c_void_p()
         ffi.check(dl.lib.sgc_sample_begin(dl.ctx, C.byref(smp), 0, 30, 1))
         ffi.check(dl.lib.sgc_sample_push_packed(smp, big.data_ptr(), big.numel(), ffi.MEM_DEVICE))

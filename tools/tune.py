@@ -16,6 +16,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # dbg=... ablation flags need a library built with SGC_HIPCC_FLAGS=-DSGC_ABLATE=1 (python -c "from sgcount_amd import build as b; b.build_one(b.SO, force=True)")
 
 
+def synth_mode(dominant):
+    from sgcount_amd import synth
+    return synth.MODE_FIXED | synth.mode_dominant(dominant)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=100_000_000)
@@ -25,6 +30,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--workload", choices=["1mm", "exact"], default="1mm")
     ap.add_argument("--nocheck", action="store_true")
+    ap.add_argument("--dominant", type=int, default=0, help="percent of the reads that draw ONE guide (synth.mode_dominant)")
     ap.add_argument("--notiming", action="store_true", help="leave the library's per-kernel events off (wall time only)")
     ap.add_argument("--opts", default="", help="extra options k=v,k=v applied to all variants")
     ap.add_argument("--lib-opts", default="", help="options k=v,k=v applied BEFORE the tables are built (align_slices, rest_filter, ...)")
@@ -32,7 +38,8 @@ def main():
     import torch
     from sgcount_amd.workload import DeviceWorkload
     lib_opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in filter(None, args.lib_opts.split(","))}
-    wl = DeviceWorkload(args.reads, args.guides, 20, one_mismatch=args.workload == "1mm", lib_options=lib_opts)
+    wl = DeviceWorkload(args.reads, args.guides, 20, one_mismatch=args.workload == "1mm", lib_options=lib_opts,
+                        **({"mode": synth_mode(args.dominant)} if args.dominant else {}))
     for kv in filter(None, args.opts.split(",")):
         k, v = kv.split("=")
         wl.dl.set_option(k, int(v))
@@ -49,7 +56,7 @@ def main():
         for v in variants:
             wl.dl.set_option("variant", specs[v][0])
             wl.dl.set_option("dbg", 0)
-            for k in ("cuckoo", "dense", "tag_sub", "direct", "six_byte", "five_byte"):          # (place_trials is per context: --opts place_trials=1 turns the trials off)          # per-variant toggles start from their defaults
+            for k in ("cuckoo", "dense", "tag_sub", "direct", "six_byte", "five_byte", "balanced"):          # (place_trials is per context: --opts place_trials=1 turns the trials off)          # per-variant toggles start from their defaults
                 wl.dl.set_option(k, 1)
             for k, val in specs[v][1]:
                 wl.dl.set_option(k, int(val))
@@ -61,6 +68,9 @@ def main():
                 wl.step()
             e1.record()
             torch.cuda.synchronize()
+            if any(k == "dbg" and int(val) & 1048576 for k, val in specs[v][1]):
+                sys.stdout.flush()
+                wl.dl.set_option("timeline_dump", 1)       # a -DSGC_STAMPS=1 library: "TL" lines of the last pass (tools/wg_timeline.py)
             t = wl.dl.timing(reset=True)
             counts, total, matched = wl.result()
             h = hashlib.sha256(counts.tobytes()).hexdigest()[:12] + ":%d:%d" % (total, matched)
