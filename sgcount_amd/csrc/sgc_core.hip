@@ -64,11 +64,11 @@ __device__ __forceinline__ void starts_from_totals(const uint32_t *__restrict__ 
 }
 
 #if SGC_STAMPS
-static __device__ sgc_tl_row tl_core[2][SGC_TL_MAXWG];
+static __device__ sgc_tl_row tl_core_a[SGC_TL_MAXWG], tl_core_b[SGC_TL_MAXWG];
 #endif
 void sgc_core_timeline_dump() {
 #if SGC_STAMPS
-    SGC_TIMELINE_DUMP(tl_core[0], "coreA"); SGC_TIMELINE_DUMP(tl_core[1], "coreB");
+    SGC_TIMELINE_DUMP(tl_core_a, "coreA"); SGC_TIMELINE_DUMP(tl_core_b, "coreB");
 #endif
 }
 
@@ -136,14 +136,22 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             const uint64_t *ge = cv.ents + (size_t)p * SGC_CORE_EMAX;
             const uint32_t *gg = cv.gids + (size_t)p * SGC_CORE_EMAX;
             const uint32_t *gs = reinterpret_cast<const uint32_t *>(cv.starts + (size_t)p * SGC_CORE_STARTS);
-            for (uint32_t i = t; i < SGC_CORE_EMAX; i += KC_THREADS) { ent[i] = ge[i]; tgid[i] = gg[i]; cnt[i] = 0; }
-            for (uint32_t i = t; i < SGC_CORE_STARTS / 2; i += KC_THREADS) reinterpret_cast<uint32_t *>(start)[i] = gs[i];
+            // (every load of the staging first, into registers, then the stores: written load, store, load, store the loops run in
+            // that order, each iteration a round trip to memory of its own)
+            static_assert(SGC_CORE_EMAX == 2 * KC_THREADS && SGC_CORE_STARTS / 2 <= 3 * KC_THREADS, "the staging below is unrolled by hand");
+            const uint64_t e0 = ge[t], e1 = ge[t + KC_THREADS];
+            const uint32_t g0 = gg[t], g1 = gg[t + KC_THREADS];
+            const uint32_t s0 = gs[t], s1 = gs[t + KC_THREADS], s2 = t + 2 * KC_THREADS < SGC_CORE_STARTS / 2 ? gs[t + 2 * KC_THREADS] : 0u;
+            const uint32_t sc = t < in.W ? in.cnt[(size_t)p * in.W + t] : 0u;
+            const uint32_t so = t < in.W ? in.off[(size_t)p * in.W + t] : 0u;
+            ent[t] = e0; ent[t + KC_THREADS] = e1; tgid[t] = g0; tgid[t + KC_THREADS] = g1; cnt[t] = 0; cnt[t + KC_THREADS] = 0;
+            reinterpret_cast<uint32_t *>(start)[t] = s0; reinterpret_cast<uint32_t *>(start)[t + KC_THREADS] = s1;
+            if (t + 2 * KC_THREADS < SGC_CORE_STARTS / 2) reinterpret_cast<uint32_t *>(start)[t + 2 * KC_THREADS] = s2;
             // the partition's segments, one per producer workgroup (in.W <= KC_THREADS)
             uint32_t seg_total;
-            const uint32_t sc = t < in.W ? in.cnt[(size_t)p * in.W + t] : 0u;
             const uint32_t sp = wg_scan_1024(sc, wtmp, &seg_total);
             segpre[t] = sp;
-            segoff[t] = t < in.W ? in.off[(size_t)p * in.W + t] : 0u;
+            segoff[t] = so;
             __syncthreads();
             cur_p = p;
         }
@@ -359,7 +367,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             }
         }
     }
-    SGC_TIMELINE_END(dbg, tl_core[FINAL ? 1 : 0], c_hi - c_lo);
+    SGC_TIMELINE_END(dbg, (FINAL ? tl_core_b : tl_core_a), c_hi - c_lo);
 }
 
 // ------------------------------------------------------------------------------------------------ host side

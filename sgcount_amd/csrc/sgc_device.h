@@ -15,7 +15,7 @@
 #ifndef SGC_STAMPS
 #define SGC_STAMPS 0
 #endif
-struct sgc_tl_row { unsigned long long begin, end, cycles; uint32_t xcc, hw, extra, used; };     // cycles: s_memtime ticks over the lifetime
+struct sgc_tl_row { unsigned long long begin, end, cycles, ph[4]; uint32_t xcc, hw, extra, used; };     // cycles: s_memtime ticks over the lifetime
 #define SGC_TL_MAXWG 2048u
 __device__ __forceinline__ uint32_t sgc_xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20); }      // hwreg(HW_REG_XCC_ID, 0, 4)
 __device__ __forceinline__ uint32_t sgc_hw_id() { return __builtin_amdgcn_s_getreg((31 << 11) | 4); }       // hwreg(HW_REG_HW_ID)
@@ -23,9 +23,11 @@ __device__ __forceinline__ uint32_t sgc_hw_id() { return __builtin_amdgcn_s_getr
 #define SGC_TIMELINE_BEGIN(dbg)                                                                                                  \
     const unsigned long long tl_begin_ = (SGC_STAMPS && ((dbg) & 1048576u)) ? __builtin_amdgcn_s_memrealtime() : 0ull,             \
                              tl_cyc_ = (SGC_STAMPS && ((dbg) & 1048576u)) ? __builtin_amdgcn_s_memtime() : 0ull
-#define SGC_TIMELINE_END(dbg, buf, extra_)                                                                                       \
+#define SGC_TIMELINE_END(dbg, buf, extra_) SGC_TIMELINE_END4(dbg, buf, extra_, 0, 0, 0, 0)
+#define SGC_TIMELINE_END4(dbg, buf, extra_, p0, p1, p2, p3)                                                                     \
     if (SGC_STAMPS && ((dbg) & 1048576u) && threadIdx.x == 0 && blockIdx.x < SGC_TL_MAXWG) {                                      \
         sgc_tl_row row_;                                                                                                          \
+        row_.ph[0] = (p0); row_.ph[1] = (p1); row_.ph[2] = (p2); row_.ph[3] = (p3);                                               \
         row_.begin = tl_begin_; row_.end = __builtin_amdgcn_s_memrealtime(); row_.xcc = sgc_xcc_id(); row_.hw = sgc_hw_id();     \
         row_.extra = (uint32_t)(extra_); row_.used = 1; row_.cycles = __builtin_amdgcn_s_memtime() - tl_cyc_;                                                                           \
         buf[blockIdx.x] = row_;                                                                                                   \
@@ -33,6 +35,7 @@ __device__ __forceinline__ uint32_t sgc_hw_id() { return __builtin_amdgcn_s_getr
 #else
 #define SGC_TIMELINE_BEGIN(dbg)
 #define SGC_TIMELINE_END(dbg, buf, extra_)
+#define SGC_TIMELINE_END4(dbg, buf, extra_, p0, p1, p2, p3)
 #endif
 // SGC_EXTRA_LDS_K1 / _K2 / _CORE (environment, -DSGC_STAMPS=1 builds only): dynamic LDS added to the launches of that kernel, to
 // hold it to one workgroup per CU — the occupancy experiments of DESIGN.md
@@ -54,7 +57,7 @@ static inline unsigned sgc_extra_lds(const char *which) {
         (void)hipDeviceSynchronize();                                                                                             \
         if (hipMemcpyFromSymbol(h_, HIP_SYMBOL(buf), sizeof h_) != hipSuccess) break;                                             \
         for (uint32_t i_ = 0; i_ < SGC_TL_MAXWG; i_++)                                                                            \
-            if (h_[i_].used) printf("TL %s wg %u xcc %u hw %x begin %llu end %llu extra %u cycles %llu\n", name, i_, h_[i_].xcc, h_[i_].hw, h_[i_].begin, h_[i_].end, h_[i_].extra, h_[i_].cycles); \
+            if (h_[i_].used) printf("TL %s wg %u xcc %u hw %x begin %llu end %llu extra %u cycles %llu ph %llu %llu %llu %llu\n", name, i_, h_[i_].xcc, h_[i_].hw, h_[i_].begin, h_[i_].end, h_[i_].extra, h_[i_].cycles, h_[i_].ph[0], h_[i_].ph[1], h_[i_].ph[2], h_[i_].ph[3]); \
         memset(h_, 0, sizeof h_);                                                                                                 \
         (void)hipMemcpyToSymbol(HIP_SYMBOL(buf), h_, sizeof h_);                                                                  \
     } while (0)

@@ -234,7 +234,9 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
                         // the partition's blocks from this workgroup, in order: k_count_slices walks these lists
                         // instead of scanning every descriptor
                         uint32_t *wl = wlist + ((size_t)blockIdx.x * PART_ARR + q) * blocks_per_wg + nblk[q];
-                        for (uint32_t i = 0; i < nb; i++) wl[i] = x + i;
+                        // (block id << 11 | fill: every block is full except the one that is open when the workgroup ends, whose
+                        // entry is corrected there — k_count_slices needs no second, dependent load of the descriptor)
+                        for (uint32_t i = 0; i < nb; i++) wl[i] = ((x + i) << 11) | PART_BLOCK;
                         nblk[q] += nb;
                         blk[q] = x + nb - 1;
                         rn.w = x * PART_BLOCK - (st0 + head);
@@ -273,7 +275,10 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
         }
         __syncthreads();
     }
-    if (t <= P && blk[t] != 0xFFFFFFFFu) desc[blk[t]] = ((t + 1) << 16) | fill[t];
+    if (t <= P && blk[t] != 0xFFFFFFFFu) {
+        desc[blk[t]] = ((t + 1) << 16) | fill[t];
+        wlist[((size_t)blockIdx.x * PART_ARR + t) * blocks_per_wg + nblk[t] - 1u] = (blk[t] << 11) | fill[t];
+    }
     // the blocks this workgroup never handed out read as "no partition, no records"; workgroup 0 also clears the
     // scratch counters behind the descriptors (no separate memset on the stream)
     for (uint32_t i = next_free + t; i < blocks_per_wg; i += K1_THREADS) desc[block0 + i] = 0;
@@ -384,9 +389,9 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     for (uint32_t i = t; i < RUN_MAXP; i += K2_THREADS) hn[i] = 0;
     if (t < 2 * K2_U * BPS) miss_cnt[t / (K2_U * BPS)][t % (K2_U * BPS)] = 0;
     // diagnostic stamps (SGC_STAMPS && (dbg & 512)): cycle counts of the phases of a few workgroups, printed at the end
-    unsigned long long ts0 = 0, ts_scan = 0, ts_loop = 0;
+    unsigned long long ts0 = 0, ts_scan = 0, ts_loop = 0, ts_flush = 0;
     uint32_t n_groups_dbg = 0;
-    if (SGC_STAMPS && (dbg & 512)) ts0 = __builtin_amdgcn_s_memtime();
+    if (SGC_STAMPS && (dbg & (512u | 1048576u))) ts0 = __builtin_amdgcn_s_memtime();
     // Which blocks of which slice.  K1 workgroup w handed slice p wcnt[w][p] blocks, listed in wlist[w][p][]: in that order
     // (w major) the slice's blocks form one sequence.
     //   static (slice_tot == nullptr): workgroup (p, g) = (blockIdx / G, blockIdx % G) takes the g-th of G equal shares of
@@ -435,27 +440,42 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
         p = blockIdx.x / G; g = blockIdx.x % G;
     }
     __syncthreads();                                                     // the previous segment is done with tab[], cnt[], pre[], wmiss4[]
-    const ulonglong2 *gtab = reinterpret_cast<const ulonglong2 *>(gslots) + (uint64_t)p * (slice / 2);
-    for (uint32_t i = t; i < S / 2; i += K2_THREADS) {      // bare keys in LDS (a key is < 2^60, so SGC_EMPTY stays distinct)
-        ulonglong2 v = i < slice / 2 ? gtab[i] : make_ulonglong2(SGC_EMPTY, SGC_EMPTY);
-        if (v.x != SGC_EMPTY) v.x >>= gid_bits;
-        if (v.y != SGC_EMPTY) v.y >>= gid_bits;
-        tab[i] = v;
+    // What a segment needs from memory before its first record — the block counts of the slice and the slice itself — is requested
+    // together and waited for once (the staging loop written load, store, load, store runs in that order: a round trip per iteration).
+    const uint32_t wc = t < k1_wgs ? wcnt[t * PART_ARR + p] : 0u;
+    {
+        const ulonglong2 *gtab = reinterpret_cast<const ulonglong2 *>(gslots) + (uint64_t)p * (slice / 2);
+        constexpr uint32_t NI = S / 2 / K2_THREADS;
+        ulonglong2 v[NI];
+#pragma unroll
+        for (uint32_t k = 0; k < NI; k++) {
+            const uint32_t i = k * K2_THREADS + t;
+            v[k] = i < slice / 2 ? gtab[i] : make_ulonglong2(SGC_EMPTY, SGC_EMPTY);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < NI; k++) {      // bare keys in LDS (a key is < 2^60, so SGC_EMPTY stays distinct)
+            if (v[k].x != SGC_EMPTY) v[k].x >>= gid_bits;
+            if (v[k].y != SGC_EMPTY) v[k].y >>= gid_bits;
+            tab[k * K2_THREADS + t] = v[k];
+        }
     }
     for (uint32_t i = t; i < S; i += K2_THREADS) cnt[i] = 0;
     {
         uint32_t Bp;
-        pre[t] = wg_scan_1024(t < k1_wgs ? wcnt[t * PART_ARR + p] : 0u, wtmp, &Bp);
+        pre[t] = wg_scan_1024(wc, wtmp, &Bp);
         __syncthreads();
         if (!balanced) { s_lo = (uint32_t)((uint64_t)Bp * g / G); s_hi = (uint32_t)((uint64_t)Bp * (g + 1) / G); }
         else if (!SGC_BOUND(s_hi <= Bp, reinterpret_cast<unsigned long long *>(matched) + 3, 12)) s_hi = s_lo;      // k_partition's totals and its lists disagree
     }
     first_seg = false;
     run0 = 0;
-    stretch = (s_hi - s_lo) * PART_BLOCK;                         // no run can lack room: as long as all blocks of the share
+    stretch = (s_hi - s_lo) * PART_BLOCK;                         // no run can lack room: as many records as all blocks of the share hold
     if (DENSE) {
         if (t < 4) wmiss4[t] = 0;
-        if (t == 0) { wmiss = 0; mbase = s_hi > s_lo ? atomicAdd(mcur, DIRECT ? stretch << sub_bits : stretch) : 0u; }
+        // where the runs go: with balanced shares the segments cut the sequence of all slice blocks into disjoint pieces, so the
+        // piece's first block IS a bump allocator's answer (no atomic on one word from every workgroup of the launch)
+        if (t == 0) { wmiss = 0; mbase = balanced ? ((spre[p] + s_lo) * PART_BLOCK) << sub_bits
+                                                  : (s_hi > s_lo ? atomicAdd(mcur, DIRECT ? stretch << sub_bits : stretch) : 0u); }
         __syncthreads();
         run0 = mbase;
     }
@@ -464,14 +484,15 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
         __syncthreads();                               // the previous round is done with list[]
         for (uint32_t i = t; i < nl; i += K2_THREADS) {
             const uint32_t o = win + i, w = find_extent<10>(pre, k1_wgs, o);
-            uint32_t b = wlist[((size_t)w * PART_ARR + p) * blocks_per_wg + (o - pre[w])];
+            const uint32_t e = wlist[((size_t)w * PART_ARR + p) * blocks_per_wg + (o - pre[w])];       // block id << 11 | fill
+            uint32_t b = e >> 11;
             unsigned long long *const err = reinterpret_cast<unsigned long long *>(matched) + 3;      // the sample's flag word behind `matched`
             if (!SGC_BOUND(b < k1_wgs * blocks_per_wg && w < k1_wgs, err, 9)) b = 0;
-            const uint32_t fl = desc[b] & DESC_FILL_MASK;
+            const uint32_t fl = e & 2047u;
             list[i] = (b << 11) | ((SGC_BOUND(fl >= 1u && fl <= PART_BLOCK, err, 10) ? fl : 1u) - 1u);
         }
         __syncthreads();
-        if (SGC_STAMPS && (dbg & 512)) { ts_scan += __builtin_amdgcn_s_memtime() - ts0; ts0 = __builtin_amdgcn_s_memtime(); n_groups_dbg += (nl + K2_U * (K2_THREADS / PART_BLOCK) - 1) / (K2_U * (K2_THREADS / PART_BLOCK)); }
+        if (SGC_STAMPS && (dbg & (512u | 1048576u))) { ts_scan += __builtin_amdgcn_s_memtime() - ts0; ts0 = __builtin_amdgcn_s_memtime(); n_groups_dbg += (nl + K2_U * (K2_THREADS / PART_BLOCK) - 1) / (K2_U * (K2_THREADS / PART_BLOCK)); }
         // software pipeline over groups of K2_U blocks: `cur` is processed while `nxt` is in flight.  Block ids and
         // fills are wave-uniform (scalar registers).
         uint64_t cur[Q], nxt[Q];
@@ -585,7 +606,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             }
         }
         __syncthreads();
-        if (SGC_STAMPS && (dbg & 512)) { ts_loop += __builtin_amdgcn_s_memtime() - ts0; ts0 = __builtin_amdgcn_s_memtime(); }
+        if (SGC_STAMPS && (dbg & (512u | 1048576u))) { ts_loop += __builtin_amdgcn_s_memtime() - ts0; ts0 = __builtin_amdgcn_s_memtime(); }
     }
     if ((SGC_STAMPS && (dbg & 512)) && t == 0 && (blockIdx.x % 97) == 0)
         printf("K2 wg %u slice %u: scan %llu loop %llu cycles, %u groups\n", blockIdx.x, p, ts_scan, ts_loop, n_groups_dbg);
@@ -605,6 +626,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
         ep.off[(size_t)q * ep.W + g] = (uint32_t)(mrun - ep.recs) + run0 + t * stretch;
         if (c) atomicAdd(&ep.tot[q], c);
     }
+    if (SGC_STAMPS && (dbg & 1048576u)) { __syncthreads(); ts_flush += __builtin_amdgcn_s_memtime() - ts0; ts0 = __builtin_amdgcn_s_memtime(); }
     }       // segments
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
     __shared__ unsigned long long wsum;
@@ -613,7 +635,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     if ((t & 63) == 0 && local) atomicAdd(&wsum, (unsigned long long)local);
     __syncthreads();
     if (t == 0 && wsum) atomicAdd(matched, wsum);
-    SGC_TIMELINE_END(dbg, tl_k2loop, s_hi - s_lo);
+    SGC_TIMELINE_END4(dbg, tl_k2loop, s_hi - s_lo, ts_scan, ts_loop, ts_flush, 0);
     if (!ep.recs || SGC_DBG(dbg, 262144u)) return;
     // Epilogue (sgc_runs.h): what this workgroup could not settle — the misses it compacted to the fronts of its blocks —
     // and its share of the generic partition's blocks (records with an 'N' or a dead window: nothing to probe here) go to
@@ -641,8 +663,9 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                     const bool gen = i >= nl;
                     const uint32_t *prefix = gen ? preg : pre;
                     const uint32_t o = gen ? wg + (i - nl) : ws + i, w = find_extent<10>(prefix, k1_wgs, o);
-                    const uint32_t b = wlist[((size_t)w * PART_ARR + (gen ? Pg : p)) * blocks_per_wg + (o - prefix[w])];
-                    const uint32_t e = (b << 11) | (desc[b] & DESC_FILL_MASK);       // fill <= PART_BLOCK = 1024 < 2^11
+                    const uint32_t we = wlist[((size_t)w * PART_ARR + (gen ? Pg : p)) * blocks_per_wg + (o - prefix[w])], b = we >> 11;
+                    // a generic block holds what k_partition put there; a slice block (not DENSE) the misses this kernel compacted to its front
+                    const uint32_t e = gen ? we : (b << 11) | (desc[b] & DESC_FILL_MASK);
                     if (gen) glist[i - nl] = e; else list[i] = e;
                 }
                 __syncthreads();
@@ -712,7 +735,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                             (t < (n_slices << sub_bits) ? k2_slice_wgs(spre, t >> sub_bits, NW, T_all) : 0u) + blockIdx.x,
                         hn, rcur, wtmp, &rbase);
     }
-    SGC_TIMELINE_END(dbg, tl_k2, s_hi - s_lo);
+    SGC_TIMELINE_END4(dbg, tl_k2, s_hi - s_lo, ts_scan, ts_loop, ts_flush, __builtin_amdgcn_s_memtime() - ts0);
 }
 
 // ------------------------------------------------------------------------------------------------ K3

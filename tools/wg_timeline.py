@@ -16,7 +16,7 @@ import re
 import statistics
 import sys
 
-PAT = re.compile(r"^TL (\S+) wg (\d+) xcc (\d+) hw ([0-9a-f]+) begin (\d+) end (\d+) extra (\d+)(?: cycles (\d+))?")
+PAT = re.compile(r"^TL (\S+) wg (\d+) xcc (\d+) hw ([0-9a-f]+) begin (\d+) end (\d+) extra (\d+)(?: cycles (\d+))?(?: ph (\d+) (\d+) (\d+) (\d+))?")
 
 
 def main():
@@ -24,7 +24,7 @@ def main():
     for line in open(sys.argv[1]):
         m = PAT.match(line)
         if m:
-            rows[m.group(1)].append((int(m.group(5)), int(m.group(6)), int(m.group(2)), int(m.group(3)), int(m.group(4), 16), int(m.group(7)), int(m.group(8) or 0)))
+            rows[m.group(1)].append((int(m.group(5)), int(m.group(6)), int(m.group(2)), int(m.group(3)), int(m.group(4), 16), int(m.group(7)), int(m.group(8) or 0), tuple(int(m.group(k) or 0) for k in (9, 10, 11, 12))))
     for name, rs in rows.items():
         rs.sort()
         # launches of one kernel are >= 0.25 ms apart (the other kernels of the pass run between them)
@@ -57,6 +57,9 @@ def main():
         if any(r[6] for r in rs):
             mhz = [r[6] / ((r[1] - r[0]) / 100) for r in rs if r[1] - r[0] > 1000]
             print("   s_memtime ticks per us of lifetime: min %.0f median %.0f max %.0f" % (min(mhz), statistics.median(mhz), max(mhz)))
+        if any(any(r[7]) for r in rs):
+            tick = statistics.median(mhz) if any(r[6] for r in rs) else 2300.0
+            print("   phases (s_memtime ticks -> us), mean over workgroups: " + "  ".join("%.1f" % (statistics.mean(r[7][k] for r in rs) / tick) for k in range(4)))
         ex = [r[5] for r in rs]
         if len(set(ex)) > 1:
             mx = statistics.mean(ex)
