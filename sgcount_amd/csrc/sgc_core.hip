@@ -122,6 +122,10 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
     const uint32_t hm = (uint32_t)((1ull << (2 * (L - cl))) - 1ull);   // a rest has L - cl bases
     uint32_t local = 0, cur_p = 0xFFFFFFFFu, wlo = 0;
     unsigned long long ts_unp = 0, ts_scan = 0, ts_dec = 0, ts_out = 0, ts_begin = __builtin_amdgcn_s_memtime();
+    // phases of the timeline rows (dbg 1048576; thread 0's view): staging of partitions | chunk prologues (segment search, loads issued,
+    // the barrier of the chunk) | record iterations | epilogue
+    unsigned long long tp_stage = 0, tp_chunk = 0, tp_iter = 0, tp_x = ts_begin;
+#define KC_PHASE(acc) if (SGC_STAMPS && (dbg & 1048576u)) { const unsigned long long x_ = __builtin_amdgcn_s_memtime(); acc += x_ - tp_x; tp_x = x_; }
     uint32_t n_it = 0;
     for (uint32_t ch = c_lo; ch < c_hi; ch++) {
         const uint32_t p = find_extent<SGC_CORE_MAX_LOG2_P>(cs_, P, ch);
@@ -154,6 +158,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             segoff[t] = so;
             __syncthreads();
             cur_p = p;
+            KC_PHASE(tp_stage)
         }
         // [lo, hi): the chunk in the partition-ordered numbering of all records; x0: its first record inside the partition
         const uint32_t x0 = (ch - cs_[p]) * KC_CHUNK;
@@ -180,6 +185,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             KC_LOAD(r0, 0u) KC_LOAD(r1, 1u) KC_LOAD(r2, 2u) KC_LOAD(r3, 3u)
 #undef KC_LOAD
         }
+        KC_PHASE(tp_chunk)
 #pragma unroll 1
         for (uint32_t i0 = lo; i0 < hi; i0 += KC_THREADS) {
             const bool valid = i0 + t < hi;
@@ -337,6 +343,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             }
             if (SGC_STAMPS && (dbg & 512)) { const unsigned long long x = __builtin_amdgcn_s_memtime(); ts_out += x - tsa; }
         }
+        KC_PHASE(tp_iter)
     }
     if ((SGC_STAMPS && (dbg & 512)) && (t & 63) == 0 && (blockIdx.x % 101) == 0 && (t >> 6) < 2)
         printf("k_core<%d> wg %u wave %u: %u iters, load+unpack %llu scan %llu decide %llu out %llu total %llu ticks\n", (int)FINAL,
@@ -367,7 +374,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             }
         }
     }
-    SGC_TIMELINE_END(dbg, (FINAL ? tl_core_b : tl_core_a), c_hi - c_lo);
+    SGC_TIMELINE_END4(dbg, (FINAL ? tl_core_b : tl_core_a), c_hi - c_lo, tp_stage, tp_chunk, tp_iter, __builtin_amdgcn_s_memtime() - tp_x);
 }
 
 // ------------------------------------------------------------------------------------------------ host side
