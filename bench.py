@@ -58,6 +58,7 @@ def parse_args(argv=None):
     ap.add_argument("--e2e-reads", type=int, default=100_000_000, help="reads of the end-to-end FASTQ leg; 0 disables it")
     ap.add_argument("--e2e-gz-reads", type=int, default=10_000_000, help="reads of the .gz end-to-end leg; 0 disables it")
     ap.add_argument("--e2e-dir", default=None, help="where the FASTQ text is written (default: /dev/shm or /tmp)")
+    ap.add_argument("--dominant", type=int, default=40, help="percent of the reads of the skewed-sample leg that draw ONE guide; 0 disables the leg")
     ap.add_argument("--placement-trials", type=int, default=1, help="0: skip the second timed region that prices the opt-in placement trials (profiling runs)")
     return ap.parse_args(argv)
 
@@ -613,6 +614,32 @@ def main():
         out["exchange"] = exch
     if placement:
         out["placement_trials"] = placement
+    if world == 1 and args.dominant and args.reads >= (1 << 25):
+        # A sample that one guide dominates (synth.mode_dominant: a screen after strong selection): with the same number of workgroups
+        # for every library slice the slice of that guide decides the kernel's time; the shipped pass deals ALL slice blocks out in
+        # equal shares (`balanced`).  Same steps, its own resident sample; not part of `value`.
+        wl2 = DeviceWorkload(args.reads, args.guides, L, one_mismatch=not exact, position_recursion=recursion, offset=offset,
+                             reads_seed=synth.READS_SEED, device_index=dev_index, mode=synth.MODE_FIXED | synth.mode_dominant(args.dominant))
+        skew = {"percent_of_reads_on_one_guide": args.dominant, "reads": args.reads}
+        tables = []
+        for name, bal in (("balanced_shares", 1), ("equal_workgroups_per_slice", 0)):
+            wl2.dl.set_option("balanced", bal)
+            for _ in range(2):
+                wl2.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                wl2.step()
+            torch.cuda.synchronize()
+            skew[name] = {"ms_per_step": 1e3 * (time.perf_counter() - t1) / args.steps}
+            skew[name]["reads_per_s"] = args.reads / (skew[name]["ms_per_step"] * 1e-3)
+            c2, t2, m2 = wl2.result()
+            tables.append((c2.tolist(), t2, m2))
+        skew["same_table"] = tables[0] == tables[1]
+        skew["top_guide_share"] = max(tables[0][0]) / max(tables[0][1], 1)
+        skew["note"] = "shipped: balanced_shares; the other line is sgc_set_option(balanced, 0), the round-2 scheme"
+        wl2.close()
+        out["skewed_sample"] = skew
     if rank == 0:
         reads_timed = args.reads * args.steps
         # the count path is a short pipeline of kernels over the same reads; the roofline is

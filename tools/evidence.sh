@@ -9,7 +9,7 @@
 #   stamps.txt                     s_memtime phase stamps of k_count_slices / k_core (dbg 512)
 R=$GRAFT_REPO_ROOT; D=$R/gpurun_out/$1; mkdir -p $D
 cd /tmp && export TMPDIR=/tmp
-BENCH="--steps 10 --warmup 2 --cpu-seconds 0 --e2e-reads 0 --placement-trials 0"
+BENCH="--steps 10 --warmup 2 --cpu-seconds 0 --e2e-reads 0 --placement-trials 0 --dominant 0"
 for W in 1mm exact; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $D/prof_$W -- python3 $R/bench.py $BENCH --workload $W > $D/bench_prof_$W.log 2>&1 || exit 1
   cp $(ls -t $D/prof_$W/*/*kernel_stats.csv | head -1) $D/kernel_stats_$W.csv
@@ -20,8 +20,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $D/prof_ingest -- python
 cp $(ls -t $D/prof_ingest/*/*kernel_stats.csv | head -1) $D/kernel_stats_ingest.csv
 grep -e '-> records' $D/ingest_prof.log > $D/ingest.txt
 for W in 1mm exact; do
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $D/pmc_fetch_$W -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --e2e-reads 0 --placement-trials 0 --workload $W > $D/pmc_fetch_$W.log 2>&1 &&
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $D/pmc_write_$W -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --e2e-reads 0 --placement-trials 0 --workload $W > $D/pmc_write_$W.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $D/pmc_fetch_$W -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --e2e-reads 0 --placement-trials 0 --dominant 0 --workload $W > $D/pmc_fetch_$W.log 2>&1 &&
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $D/pmc_write_$W -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --e2e-reads 0 --placement-trials 0 --dominant 0 --workload $W > $D/pmc_write_$W.log 2>&1 || exit 1
 done
 cd $R && python3 tools/pmc_traffic.py $D/pmc_fetch_1mm $D/pmc_write_1mm $D/pmc_fetch_exact $D/pmc_write_exact "$1" > $D/pmc_traffic.txt && cp profiles/pmc_traffic.json $D/pmc_traffic.json
 cd /tmp
