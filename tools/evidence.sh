@@ -7,6 +7,7 @@
 #   pmc_traffic.json               HBM bytes per pass from separate --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py)
 #   sq_*.txt                       SQ counters of the count kernels (tools/pmc_table.py), one --pmc pass per group
 #   stamps.txt                     s_memtime phase stamps of k_count_slices / k_core (dbg 512)
+#   wg_timeline.txt                per kernel: lifetimes of the workgroups, slot use, phases (dbg 1048576, tools/wg_timeline.py)
 R=$GRAFT_REPO_ROOT; D=$R/gpurun_out/$1; mkdir -p $D
 cd /tmp && export TMPDIR=/tmp
 BENCH="--steps 10 --warmup 2 --cpu-seconds 0 --e2e-reads 0 --placement-trials 0 --dominant 0"
@@ -34,6 +35,8 @@ done
 # the phase stamps are compiled out of the shipped kernels (they cost scalar registers): rebuild with them for this step only
 cd $R && SGC_HIPCC_FLAGS=-DSGC_STAMPS=1 python3 -c "from sgcount_amd import build as b; b.build_one(b.SO, force=True)" &&
 python3 tools/tune.py --variants "4:dbg=512" --rounds 1 --steps 1 --nocheck 2>&1 | grep -E "^K2 wg|^k_core" > $D/stamps.txt
+# ... and the workgroup timelines of the last of four back-to-back passes (where every workgroup ran, when, and its phases)
+python3 tools/tune.py --variants "4:dbg=1048576" --rounds 1 --steps 4 --notiming --nocheck > $D/tl_raw.txt 2>&1 && python3 tools/wg_timeline.py $D/tl_raw.txt > $D/wg_timeline.txt; rm -f $D/tl_raw.txt
 python3 -c "from sgcount_amd import build as b; b.build_one(b.SO, force=True)"
 rm -rf $D/prof_* $D/pmc_fetch_* $D/pmc_write_* $D/sq[0-9] 2>/dev/null
 ls -la $D
