@@ -224,7 +224,9 @@ void sgc_free_pinned(void *p);
  * instead of the hybrid of both; next sgc_set_library), "host_routes" (1: in a hybrid ctx — sgc_lib_info.path == 2 — packed
  * records are accepted after all: the host promises to push records ONLY for reads whose span region [o - 1, o + L + 1) is all
  * ACGT and none of whose windows equals a guide with exactly one other byte up to that byte, and to push every other read as
- * bytes (sgc_sample_push_reads); the C++ scanner does), "verbose" (diagnostics on stderr).  No environment
+ * bytes (sgc_sample_push_reads); the C++ scanner does), "balanced" (default 1: the slice-count kernel deals the blocks of ALL library slices out in equal shares, so a sample that a few
+ * guides dominate costs what any other does; 0: the same number of workgroups for every slice), "verbose"
+ * (diagnostics on stderr).  No environment
  * variable changes what the library computes or which kernels it runs.  "dbg" sets
  * timing-only ablation flags / phase stamps of the kernels: they are compiled out of the shipped library, which refuses
  * a non-zero value (a profiling build — SGC_HIPCC_FLAGS=-DSGC_ABLATE=1 or -DSGC_STAMPS=1 — accepts it; results are
