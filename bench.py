@@ -253,7 +253,7 @@ def e2e_block(wl, args, exact, cpu):
         def stages_of(stats):
             smp = stats["samples"][0]
             return {"process_start_to_count_s": stats.get("process_start_to_count_s"), "library_load_s": stats["library_load_s"],
-                    "device_init_s": stats.get("device_init_s"), "table_build_s": stats["table_build_s"],
+                    "hip_runtime_wait_s": stats.get("hip_runtime_wait_s"), "device_init_s": stats.get("device_init_s"), "table_build_s": stats["table_build_s"],
                     "sample_s": smp["wall_s"], "table_write_s": stats["table_write_s"], "context_free_s": stats.get("context_free_s"),
                     "process_exit_s": stats.get("teardown_s"),
                     "feeder_setup_s": smp.get("feeder_setup_s"), "first_push_s": smp.get("first_push_s"),
@@ -367,8 +367,10 @@ def e2e_block(wl, args, exact, cpu):
                          "zlib_inflate_alone_s": inflate_s, "prepare_s": prep, "wall_s_all_runs": [r[0] for r in gz_runs],
                          "parallel_gzip": bool(smp.get("parallel_gzip")), "inflate_threads": smp["reader_threads"],
                          "gzip_chunks_decoded_in_order": smp.get("gzip_chunks_decoded_in_order"),
+                         "stages": stages_of(stats),
                          "note": "ONE deflate stream (16 members written by 16 gzip processes, no BGZF size fields): zlib on one core inflates "
-                                 "it at ~%.2f GB/s of text; here its chunks are decoded speculatively by %d threads and stitched in order"
+                                 "it at ~%.2f GB/s of text; here its chunks are decoded speculatively by %d threads, stitched in order and packed into records by "
+                                 "the same threads (the host scan: nothing of it needs the device, so it runs while the device starts up and the tables are built)"
                                  % (inflated / inflate_s / 1e9, smp["reader_threads"])}
             if cpu:
                 r = smp["reads"]

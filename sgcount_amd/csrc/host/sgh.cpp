@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <future>
 #include <thread>
 #include <unordered_set>
 
@@ -763,7 +764,7 @@ __attribute__((target("avx2"))) static void resolve_symbols_avx2(const uint16_t 
     for (; i < m; i++) dst[i] = lut[src[i]];
 }
 #endif
-static void resolve_symbols(const uint16_t *src, size_t m, const uint8_t *lut, uint8_t *dst) {
+void resolve_symbols(const uint16_t *src, size_t m, const uint8_t *lut, uint8_t *dst) {
 #if defined(__x86_64__)
     static const bool avx2 = __builtin_cpu_supports("avx2");
     if (avx2) { resolve_symbols_avx2(src, m, lut, dst); return; }
@@ -1100,7 +1101,8 @@ static void count_fastq_scan(sgc_sample *smp, FastqScanner &scan, SampleStats *s
     push_routed();
     sgc_check(sgc_sample_wait_uploads(smp, 0), "sgc_sample_wait_uploads");         // the ring is freed on return
     if (st) {
-        st->text_bytes = scan.file_size; st->reader_threads = scan.n_threads;
+        st->text_bytes = scan.gz_mode ? 0 : scan.file_size; st->reader_threads = scan.n_threads;
+        st->gz = scan.gz_mode; st->pgz = scan.gz_mode; st->pgz_fallbacks = scan.pgz_fallbacks;
         st->read_busy_s = scan.busy_s; st->read_wait_s = scan.wait_s; st->push_s = t_push; st->upload_wait_s = t_upwait;
         st->feeder_setup_s = t_a1 - t_a0; st->host_copy_s = t_copy; st->scan_path = true; st->scan_mapped = scan.used_mapping();
     }
@@ -1179,6 +1181,10 @@ static SampleCounts count_sample(sgc_ctx *ctx, const std::string &path, const Of
 void count(const CountOptions &opt_in) {
     CountOptions opt = opt_in;
     const double t_start = now_s(), t_start_unix = unix_s();
+    // The HIP runtime takes 0.06-0.14 s to come up, whoever calls it first: it does so on a thread of its own from the very start,
+    // beside the library load, the checks of the inputs and the first blocks of the scanners (nothing of it is observable before
+    // sgc_init reports a missing device, below, where the reference would have started counting).
+    std::future<int> n_dev_f = std::async(std::launch::async, [] { return sgc_device_count(); });
     const Library library = Library::from_path(opt.library_path);                      // count.rs:87
     if (opt.genemap) {                                                                 // count.rs:90-95
         if (const std::string *missing = opt.genemap->missing_alias(library))
@@ -1198,11 +1204,7 @@ void count(const CountOptions &opt_in) {
     // stream, scratch and table copy — ~0.15 GB at 100k guides), dealt round-robin over the visible GPUs: with -t N
     // the samples of one GPU overlap too (one sample's inflate and parse run beside another's kernels), which is
     // what the reference's rayon pool over samples gives on CPU cores.
-    int n_dev = sgc_device_count();
-    if (n_dev < 1) n_dev = 1;                                     // sgc_init below reports the missing device
-    if (opt.max_devices > 0) n_dev = std::min(n_dev, (int)opt.max_devices);
     const size_t n_workers = std::max<size_t>(1, std::min(opt.threads, opt.input_paths.size()));
-    const size_t n_ctx = std::min(opt.input_paths.size(), std::max<size_t>((size_t)n_dev, n_workers));
     const size_t hw = usable_cpus();
     if (opt.io_threads == 0) {
         opt.io_threads = std::max<size_t>(1, std::min<size_t>(8, hw / n_workers));
@@ -1235,6 +1237,11 @@ void count(const CountOptions &opt_in) {
     if (packable)
         for (size_t i = 0; i < std::min(n_workers, opt.input_paths.size()); i++)
             if (opt.offsets[i].index <= 0xFFFFFFFFull) scanners[i] = make_scanner(i);
+    int n_dev = n_dev_f.get();
+    if (n_dev < 1) n_dev = 1;                                     // sgc_init below reports the missing device
+    if (opt.max_devices > 0) n_dev = std::min(n_dev, (int)opt.max_devices);
+    const size_t n_ctx = std::min(opt.input_paths.size(), std::max<size_t>((size_t)n_dev, n_workers));
+    const double t_runtime = now_s();
     std::string flat;
     flat.reserve(library.seqs.size() * library.size);
     for (const auto &s : library.seqs) flat += s;
@@ -1335,10 +1342,13 @@ void count(const CountOptions &opt_in) {
         if (!f) throw Error("cannot create the stats file: " + opt.stats_path);
         std::string per_dev;
         for (size_t d = 0; d < dev_build_s.size(); d++) { char b[48]; snprintf(b, sizeof(b), "%s%.6f", d ? ", " : "", dev_build_s[d]); per_dev += b; }
-        fprintf(f, "{\"library_load_s\": %.6f, \"table_build_s\": %.6f, \"samples_s\": %.6f, \"table_write_s\": %.6f, \"total_s\": %.6f, "
+        // setup_s: everything between the library and the first sample (scanners started, HIP runtime up, contexts, tables);
+        // hip_runtime_wait_s / device_init_s / table_build_s are its parts (the runtime comes up on its own thread from the start:
+        // what is reported is what the main thread still waited for)
+        fprintf(f, "{\"library_load_s\": %.6f, \"setup_s\": %.6f, \"hip_runtime_wait_s\": %.6f, \"table_build_s\": %.6f, \"samples_s\": %.6f, \"table_write_s\": %.6f, \"total_s\": %.6f, "
                    "\"device_init_s\": %.6f, \"context_free_s\": %.6f, \"count_entered_unix_s\": %.6f, \"stats_written_unix_s\": %.6f, "
                    "\"devices\": %d, \"contexts\": %zu, \"worker_threads\": %zu, \"table_build_per_device_s\": [%s], \"samples\": [",
-                t_lib - t_start, t_tables - t_lib, t_counted - t_tables, t_end - t_counted, t_end - t_start, init_s, t_freed - t_end, t_start_unix, unix_s(),
+                t_lib - t_start, t_tables - t_lib, t_runtime - t_lib, std::max(0.0, t_tables - t_runtime - init_s), t_counted - t_tables, t_end - t_counted, t_end - t_start, init_s, t_freed - t_end, t_start_unix, unix_s(),
                 n_dev, n_ctx, n_threads, per_dev.c_str());
         for (size_t i = 0; i < n; i++) {
             const SampleStats &x = stats[i];

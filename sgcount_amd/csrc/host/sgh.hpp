@@ -110,6 +110,8 @@ void count(const CountOptions &opt);                     // count.rs:74-148
 
 // ---- FASTQ text at speed (the byte source of count()'s text path) ----------------------------------------
 size_t count_newlines(const uint8_t *p, size_t n);
+// symbols of a speculative decode -> bytes: lut[v] = v below 256, the byte of the window in front of the chunk behind a marker (0x8000 | i)
+void resolve_symbols(const uint16_t *src, size_t m, const uint8_t *lut, uint8_t *dst);
 uint32_t crc32_fast(uint32_t crc, const uint8_t *buf, size_t len);     // zlib's crc32(), folded with carry-less multiplies where the CPU has them
 
 struct SampleStats {                    // where one sample's wall time went (host side; device side from sgc_timing)
@@ -229,13 +231,30 @@ class FastqScanner {
     // routed_bytes[routed_offs[i], routed_offs[i + 1])
     const uint8_t *routed_bytes = nullptr; const uint64_t *routed_offs = nullptr; size_t n_routed = 0;
     bool usable = true;
+    // the file is ONE gzip stream (not BGZF): its chunks are decoded speculatively by the workers (sgh_inflate.cpp, as TextFeeder::run_pgz
+    // does), resolved into a buffer of the thread's own, and packed there — no text leaves the thread, and nothing needs the device,
+    // so a .gz sample inflates while the device starts up and the tables are built
+    bool gz_mode = false;
+    size_t pgz_fallbacks = 0;           // chunks decoded in order after all (speculation failed)
     size_t file_size = 0, n_threads = 0, words = 1;
     uint64_t total_lines = 0;           // after next() returned false
     double busy_s = 0, wait_s = 0;      // Σ worker busy time; time the consumer waited for a block
   private:
     struct Block;
     void run();
-    void extract(size_t b, const uint8_t *t, size_t t_lo, size_t t_hi);
+    void run_gz();
+    // packs the sequence lines among the first n_pack line starts of blk.starts (offsets from t + lo); t[offset] is readable for
+    // offsets below t_hi, a line without a newline before text_end ends there
+    void extract(Block &blk, const uint8_t *t, size_t lo, size_t t_hi, size_t n_pack, size_t text_end);
+    // gz mode: the chain that stitches the chunks (A: deflate position and window; B: line numbers and the unfinished line)
+    static constexpr size_t GZ_MAX_LINE = 4u << 20;
+    size_t gz_chunk_bytes = 0, gz_next = 0, gz_chain = 0, gz_lines = 0;
+    uint64_t gz_pos = 0;
+    bool gz_eos = false, gz_first_known = false, gz_verified = false, gz_text_ends_nl = false;
+    uint8_t gz_first_byte = 0;
+    std::vector<uint8_t> gz_window, gz_carry;
+    struct GzPiece { uint32_t crc; uint64_t len; bool member_end; uint32_t want_crc, want_isize; };
+    std::vector<std::vector<GzPiece>> gz_pieces;
     static constexpr size_t READ_SLACK = 64u << 10;      // bytes read behind a block: the rest of its last line, and the window loads
     int source = 0;
     std::atomic<bool> auto_map{false};

@@ -27,6 +27,7 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <chrono>
@@ -186,7 +187,36 @@ FastqScanner::FastqScanner(const std::string &path_, const ScanParams &prm_, siz
     map = (const uint8_t *)m;
     (void)madvise(m, file_size, MADV_SEQUENTIAL);            // see the head of this file: no LRU activation when the blocks are unmapped
     (void)posix_fadvise(fd, 0, 0, POSIX_FADV_NOREUSE);
-    if (map[0] != '@') { usable = false; return; }          // gzip, FASTA, anything else: the other readers decide
+    words = prm.L > SGC_REC8_MAXL ? 2 : 1;
+    if (file_size >= 64 && map[0] == 0x1f && map[1] == 0x8b && map[2] == 8 && threads > 1) {
+        // gzip.  BGZF (members that announce their size: independent streams) is left to the reader that inflates members in parallel
+        // straight into pinned memory; a plain stream is decoded here, chunk by chunk
+        const bool bgzf = (map[3] & 4) && map[10] + 256u * map[11] >= 6 && map[12] == 'B' && map[13] == 'C' && map[14] == 2 && map[15] == 0;
+        if (bgzf) { usable = false; return; }
+        gz_mode = true;
+        // compressed bytes per chunk: from the file size; a block size below 1 MiB is taken literally (tests: many chunks of a small file)
+        gz_chunk_bytes = block_bytes < (1u << 20) ? std::max<size_t>(block_bytes, 512)
+                                                  : std::min<size_t>(std::max<size_t>(file_size / (threads * 4), 1u << 20), 8u << 20);
+        n_blocks = (file_size + gz_chunk_bytes - 1) / gz_chunk_bytes;
+        blocks.reset(new Block[n_blocks]);
+        gz_pieces.resize(n_blocks);
+        gz_window.assign(32768, 0);
+        n_threads = std::max<size_t>(1, std::min(threads, n_blocks));
+        for (size_t t = 0; t < n_threads; t++) workers.emplace_back([this] { run_gz(); });
+        // FASTQ or not is decided by the first byte of the TEXT
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this] { return failed || gz_first_known; });
+        if (failed || gz_first_byte != '@') {
+            stop = true;
+            lk.unlock();
+            cv.notify_all();
+            for (auto &w : workers) if (w.joinable()) w.join();
+            workers.clear();
+            usable = false;
+        }
+        return;
+    }
+    if (map[0] != '@') { usable = false; return; }          // FASTA, anything else: the other readers decide
     // trailing blank lines at the very end are not records
     end = file_size;
     while (end >= 2 && map[end - 1] == '\n' && map[end - 2] == '\n') end--;
@@ -194,7 +224,6 @@ FastqScanner::FastqScanner(const std::string &path_, const ScanParams &prm_, siz
     n_blocks = (end + block - 1) / block;
     blocks.reset(new Block[n_blocks]);
     ahead = std::max<size_t>(max_ahead, 2);
-    words = prm.L > SGC_REC8_MAXL ? 2 : 1;
     n_threads = std::max<size_t>(1, std::min(threads, n_blocks));
     for (size_t t = 0; t < n_threads; t++) workers.emplace_back([this] { run(); });
 }
@@ -275,7 +304,8 @@ void FastqScanner::run() {
                 cv.wait(lk, [&] { return stop || failed || chain > b; });
                 if (stop || failed) return;
             }
-            extract(b, t, t_lo, t_hi);
+            (void)t_lo;
+            extract(blk, t, lo, t_hi, blk.starts.size(), end);
             if (!by_read) (void)madvise((void *)(map + lo), map_hi - lo, MADV_DONTNEED);      // drop the block's page-table entries here, in parallel, not at exit
             const double dt = scan_now_s() - t0;
             {
@@ -292,12 +322,179 @@ void FastqScanner::run() {
     }
 }
 
+// gz mode: chunk k of the COMPRESSED file.  As TextFeeder::run_pgz (sgh.cpp) up to the stitching chain — speculative decode from a
+// block start found inside the chunk, accepted if that is where the chunk before ended, decoded again in order otherwise —, but the
+// resolved text goes into a buffer of the thread and is packed right there.  A second chain hands on what only the text in front
+// can tell: the number of the chunk's first line and the unfinished line it continues (`gz_carry`).
+void FastqScanner::run_gz() {
+    try {
+        for (;;) {
+            size_t k;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || failed || gz_next >= n_blocks || gz_next < gz_chain + 2 * n_threads; });
+                if (stop || failed || gz_next >= n_blocks) return;
+                k = gz_next++;
+            }
+            const double t0 = scan_now_s();
+            Block &blk = blocks[k];
+            const size_t lo = k * gz_chunk_bytes, hi = std::min(file_size, lo + gz_chunk_bytes);
+            const size_t max_out = (size_t)1 << 31;
+            static thread_local std::vector<uint16_t> sym_keep;     // kept from chunk to chunk: fresh pages cost more than decoding
+            InflateSpan span;
+            span.sym.swap(sym_keep);
+            span.sym.clear();
+            struct Keep { InflateSpan &s; std::vector<uint16_t> &k; ~Keep() { s.sym.clear(); s.sym.swap(k); } } keep{span, sym_keep};
+            auto reset_span = [&]() { span.sym.clear(); span.members.clear(); span.end_of_stream = false; span.start_bit = span.end_bit = 0; };
+            bool found = false;
+            uint64_t start = 0;
+            if (k == 0) {
+                size_t at = 10;                       // the first member's header, then its first block
+                const unsigned flg = map[3];
+                if (flg & 4) at += 2 + (size_t)(map[at] + 256u * map[at + 1]);
+                if (flg & 8) { while (at < file_size && map[at]) at++; at++; }
+                if (flg & 16) { while (at < file_size && map[at]) at++; at++; }
+                if (flg & 2) at += 2;
+                if (at >= file_size) throw Error("corrupt gzip header in " + path);
+                start = 8ull * at; found = true;
+            } else {
+                found = find_block_start(map, file_size, 8ull * lo, 8ull * hi, start);
+            }
+            if (found && inflate_span(map, file_size, start, 8ull * hi, nullptr, span, max_out) != 0) { found = false; reset_span(); }
+            // ---- chain A: the chunk's true start and the window in front of it
+            uint8_t window[32768];
+            bool empty = false, last = false;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || failed || gz_chain == k; });
+                if (stop || failed) return;
+                if (k == 0) gz_pos = start;
+                memcpy(window, gz_window.data(), 32768);
+                const uint64_t pos = gz_pos;
+                if (gz_eos || (pos >= 8ull * hi && k + 1 < n_blocks)) {
+                    empty = true;                     // the stream ended, or a block that began earlier covers this whole chunk
+                } else if (!(found && start == pos)) {
+                    lk.unlock();
+                    reset_span();
+                    const int rc = inflate_span(map, file_size, pos, 8ull * hi, k == 0 ? nullptr : window, span, max_out);
+                    if (rc != 0) throw Error(std::string(rc == -4 ? "trailing garbage behind the gzip stream in " : "corrupt gzip stream in ") + path);
+                    lk.lock();
+                    pgz_fallbacks++;
+                }
+                if (empty) reset_span();
+                else {
+                    const size_t n = span.sym.size();
+                    uint8_t *nw = gz_window.data();
+                    if (n >= 32768) {
+                        for (size_t i = 0; i < 32768; i++) { const uint16_t v = span.sym[n - 32768 + i]; nw[i] = v < 256 ? (uint8_t)v : window[v & 0x7FFFu]; }
+                    } else {
+                        memmove(nw, nw + n, 32768 - n);
+                        for (size_t i = 0; i < n; i++) { const uint16_t v = span.sym[i]; nw[32768 - n + i] = v < 256 ? (uint8_t)v : window[v & 0x7FFFu]; }
+                    }
+                    gz_pos = span.end_bit;
+                    if (span.end_of_stream) { gz_eos = true; last = true; }
+                }
+                if (k + 1 == n_blocks && !gz_eos) throw Error("truncated gzip stream in " + path);
+                gz_chain = k + 1;
+            }
+            cv.notify_all();
+            // ---- the text of the chunk, behind room for the unfinished line in front of it; CRC-32 of every member piece
+            const size_t n = span.sym.size();
+            static thread_local std::vector<uint8_t> text_keep, lut_keep;
+            constexpr size_t ROOM = 1u << 16;
+            if (text_keep.size() < ROOM + n + 64) text_keep.resize(ROOM + n + 64 + (n >> 3));
+            uint8_t *txt = text_keep.data() + ROOM;
+            if (lut_keep.size() != 65536) { lut_keep.assign(65536, 0); for (unsigned i = 0; i < 256; i++) lut_keep[i] = (uint8_t)i; }
+            memcpy(lut_keep.data() + 0x8000, window, 32768);
+            resolve_symbols(span.sym.data(), n, lut_keep.data(), txt);
+            memset(txt + n, 0, 64);
+            std::vector<GzPiece> pieces;
+            {
+                size_t done = 0, mi = 0;
+                uint32_t crc = 0;
+                uint64_t piece_len = 0;
+                while (done < n || mi < span.members.size()) {
+                    while (mi < span.members.size() && span.members[mi].at == done) {
+                        pieces.push_back(GzPiece{crc, piece_len, true, span.members[mi].crc, span.members[mi].isize});
+                        crc = 0; piece_len = 0; mi++;
+                    }
+                    if (done >= n) break;
+                    const size_t m = mi < span.members.size() ? span.members[mi].at - done : n - done;
+                    crc = crc32_fast(crc, txt + done, m);
+                    piece_len += m; done += m;
+                }
+                if (piece_len) pieces.push_back(GzPiece{crc, piece_len, false, 0, 0});
+            }
+            // line starts behind every newline of the chunk (relative to txt; one at n belongs to the next chunk)
+            std::vector<uint32_t> nls;
+            nls.reserve(n / 64 + 16);
+#if defined(__x86_64__)
+            if (have_avx2()) list_newlines_avx2(txt, 0, n, 0, nls);
+            else
+#endif
+                list_newlines_generic(txt, 0, n, 0, nls);
+            // ---- chain B: line numbers and the unfinished line
+            std::vector<uint8_t> carry;
+            size_t n_txt = n;                          // the chunk's text without trailing blank lines at the very end of the stream
+            bool final_open = false;                  // the stream ends with a line that has no newline
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || failed || gz_lines == k; });
+                if (stop || failed) return;
+                if (k == 0) { gz_first_byte = n ? txt[0] : 0; gz_first_known = true; }
+                carry = gz_carry;
+                blk.first_line = lines_so_far;
+                if (last) {
+                    // trailing blank lines at the very end are not records (as the plain scanner cuts them off its mapping)
+                    while (n_txt >= 1 && txt[n_txt - 1] == '\n' && (n_txt >= 2 ? txt[n_txt - 2] == '\n' : (carry.empty() && gz_text_ends_nl))) {
+                        n_txt--; nls.pop_back();
+                    }
+                }
+                lines_so_far += nls.size();
+                if (n_txt) gz_text_ends_nl = txt[n_txt - 1] == '\n';
+                if (nls.empty()) gz_carry.insert(gz_carry.end(), txt, txt + n_txt);
+                else gz_carry.assign(txt + nls.back(), txt + n_txt);
+                if (gz_carry.size() > GZ_MAX_LINE) throw Error("FASTQ line longer than " + std::to_string(GZ_MAX_LINE) + " bytes in " + path + " (--pack device reads lines of any length)");
+                if (last && !gz_carry.empty()) { final_open = true; lines_so_far++; }
+                gz_pieces[k] = std::move(pieces);
+                gz_lines = k + 1;
+            }
+            cv.notify_all();
+            // ---- pack: the text is (unfinished line in front) ++ (chunk); its lines that end inside the chunk
+            uint8_t *C = txt - carry.size();
+            if (carry.size() > ROOM) {                 // a very long line: a buffer of its own
+                static thread_local std::vector<uint8_t> big;
+                big.resize(carry.size() + n_txt + 64);
+                memcpy(big.data() + carry.size(), txt, n_txt);
+                memset(big.data() + carry.size() + n_txt, 0, 64);
+                C = big.data();
+            }
+            if (!carry.empty()) memcpy(C, carry.data(), carry.size());
+            const size_t clen = carry.size() + n_txt;
+            if (clen) {
+                blk.starts.reserve(nls.size() + 1);
+                blk.starts.push_back(0);
+                for (uint32_t s : nls) if (s < n_txt) blk.starts.push_back((uint32_t)(carry.size() + s));
+                const size_t n_pack = nls.size() + (final_open ? 1 : 0);
+                extract(blk, C, 0, clen, n_pack, clen);
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                blk.done = true;
+                busy_s += scan_now_s() - t0;
+            }
+            cv.notify_all();
+        }
+    } catch (const std::exception &e) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!failed) { failed = true; error = e.what(); }
+        cv.notify_all();
+    }
+}
+
 // phase 2 of block b; t[offset] is readable for offsets in [t_lo, t_hi) (the thread's buffer, or the mapping itself); what lies beyond
 // — the rest of a line longer than the slack behind the block — is taken from the mapping
-void FastqScanner::extract(size_t b, const uint8_t *t, size_t t_lo, size_t t_hi) {
-    (void)t_lo;
-    Block &blk = blocks[b];
-    const size_t lo = b * block;
+void FastqScanner::extract(Block &blk, const uint8_t *t, size_t lo, size_t t_hi, size_t n_pack, size_t text_end) {
     const size_t ns = blk.starts.size();
     const uint32_t L = prm.L, K = L + 2, o = prm.offset;
     const bool rev = prm.reverse, rec = prm.recursion;
@@ -308,7 +505,7 @@ void FastqScanner::extract(size_t b, const uint8_t *t, size_t t_lo, size_t t_hi)
     const bool fast_ok = have_avx2() && o >= 1;
     blk.recs.reserve((ns / 4 + 2) * words);
     uint64_t g = blk.first_line;
-    for (size_t i = 0; i < ns; i++, g++) {
+    for (size_t i = 0; i < n_pack; i++, g++) {
         const size_t s = lo + blk.starts[i];
         const uint32_t ph = (uint32_t)(g & 3u);
         if (ph == 0 || ph == 2) {
@@ -324,11 +521,11 @@ void FastqScanner::extract(size_t b, const uint8_t *t, size_t t_lo, size_t t_hi)
         else {
             const void *q = memchr(t + s, '\n', t_hi - s);
             if (q) e = (size_t)((const uint8_t *)q - t);
-            else if (t_hi >= end) e = end;
+            else if (t_hi >= text_end) e = text_end;
             else {                                    // the line runs past the thread's buffer: finish it on the mapping
                 src = map; src_hi = file_size;
-                const void *q2 = memchr(map + t_hi, '\n', end - t_hi);
-                e = q2 ? (size_t)((const uint8_t *)q2 - map) : end;
+                const void *q2 = memchr(map + t_hi, '\n', text_end - t_hi);
+                e = q2 ? (size_t)((const uint8_t *)q2 - map) : text_end;
             }
         }
         size_t n = e - s;
@@ -387,6 +584,20 @@ bool FastqScanner::next(const uint64_t *&recs, size_t &n_records) {
     if (consumed >= n_blocks) {
         if (!checked_end) {
             checked_end = true;
+            if (gz_mode && !gz_verified) {
+                // every byte of the stream went through a worker: the CRC-32 and ISIZE of every gzip member, piece by piece
+                gz_verified = true;
+                uint32_t crc = 0; uint64_t mlen = 0;
+                for (const auto &pcs : gz_pieces)
+                    for (const GzPiece &pc : pcs) {
+                        crc = (uint32_t)crc32_combine(crc, pc.crc, (z_off_t)pc.len);
+                        mlen += pc.len;
+                        if (pc.member_end) {
+                            if (crc != pc.want_crc || (uint32_t)mlen != pc.want_isize) throw Error("corrupt gzip stream (CRC / length mismatch) in " + path);
+                            crc = 0; mlen = 0;
+                        }
+                    }
+            }
             total_lines = lines_so_far;
             if (lines_so_far % 4 != 0) throw Panic("truncated FASTQ record in " + path);
         }

@@ -230,17 +230,22 @@ def test_plain_gzip_input_is_inflated_in_parallel(cli, tmp_path, example_library
                        ("three.fastq.gz", gzip.compress(text[:third], 1) + gzip.compress(text[third:2 * third], 9) + gzip.compress(text[2 * third:], 6))):
         p = os.path.join(str(tmp_path), name)
         open(p, "wb").write(blob)
-        rc, out, err = run(cli, "-l", LIB, "-i", p, "-a", "5", "-q", "-n", "diff", "--io-threads", "4", "--chunk-mb", "1", "--stats-json", stats)
-        assert rc == 0, err
-        assert out == want
-        s0 = json.load(open(stats))["samples"][0]
-        assert s0["text_path"] and s0["gz"] and s0["parallel_gzip"] and not s0["bgzf"] and s0["reads"] == 1101 * 60
+        # default: the host scan inflates and packs (sgh_scan.cpp run_gz); --pack fastq: the text path inflates into pinned slices and
+        # the GPU parses (TextFeeder::run_pgz) — the same speculative decoder under both
+        for pack, key in (("scan", "scan_path"), ("fastq", "text_path")):
+            rc, out, err = run(cli, "-l", LIB, "-i", p, "-a", "5", "-q", "-n", "diff", "--io-threads", "4", "--scan-threads", "4", "--chunk-mb", "1",
+                               "--pack", pack, "--stats-json", stats)
+            assert rc == 0, err
+            assert out == want
+            s0 = json.load(open(stats))["samples"][0]
+            assert s0[key] and s0["gz"] and s0["parallel_gzip"] and not s0["bgzf"] and s0["reads"] == 1101 * 60, (pack, s0)
     blob = bytearray(gzip.compress(text, 6))
     blob[len(blob) // 2] ^= 0x41
     p = os.path.join(str(tmp_path), "bad.fastq.gz")
     open(p, "wb").write(bytes(blob))
-    rc, out, err = run(cli, "-l", LIB, "-i", p, "-a", "5", "-q")
-    assert rc != 0 and ("gzip" in err or "read error" in err or "panicked" in err)
+    for pack in ("scan", "fastq"):
+        rc, out, err = run(cli, "-l", LIB, "-i", p, "-a", "5", "-q", "--pack", pack)
+        assert rc != 0 and ("gzip" in err or "read error" in err or "panicked" in err), (pack, err)
 
 
 def test_malformed_fastq_panics_like_the_reference(cli, tmp_path, example_reads):

@@ -336,11 +336,11 @@ def test_hybrid_cli_table(tmp_path):
     want = O.format_results(lib, [row], ["r"], None, False)
     import json
     stats = str(tmp_path / "stats.json")
-    for path, extra, scan in ((fq, [], True), (fq, ["--pack", "fastq"], False), (fq + ".gz", [], False), (fq, ["--scan-threads", "3", "--scan-block-kb", "8"], True)):
+    for path, extra, scan in ((fq, [], True), (fq, ["--pack", "fastq"], False), (fq + ".gz", [], True), (fq + ".gz", ["--pack", "fastq"], False), (fq, ["--scan-threads", "3", "--scan-block-kb", "8"], True)):
         p = subprocess.run([hostlib.cli_path(), "-l", lp, "-i", path, "-a", "9", "-q", "-n", "r", "--stats-json", stats] + extra, capture_output=True, timeout=300)
         assert p.returncode == 0, p.stderr.decode()
         assert p.stdout.decode() == want, (path, extra)
-        assert json.load(open(stats))["samples"][0]["scan_path"] == scan      # plain text: the scanner routes the reads near the 'N' guides itself
+        assert json.load(open(stats))["samples"][0]["scan_path"] == scan      # plain text and plain gzip: the scanner routes the reads near the 'N' guides itself
     # the other strand, no recursion, exact: the scanner's routing against the GPU's
     rtext = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, bytes((c ^ 4) if (c & 2) else (c ^ 21) for c in reversed(r)), b"I" * len(r)) for i, r in enumerate(reads))
     open(fq, "wb").write(rtext)

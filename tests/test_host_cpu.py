@@ -314,6 +314,67 @@ def test_scanner_records_equal_the_host_packer(tmp_path):
     assert e.value.code == 101 and "truncated" in str(e.value)
 
 
+def test_scanner_packs_a_gzip_stream_like_its_text(tmp_path):
+    """FastqScanner on ONE gzip stream (not BGZF): the chunks of the compressed file are decoded speculatively, stitched in order,
+    resolved into the worker's own buffer and packed there, with the unfinished line handed from chunk to chunk — the records and
+    the line count must be those of the plain text, for every chunking (chunks much smaller than a deflate block: decoded in
+    order; several members; no final newline; trailing blank lines; CRLF), and a damaged stream must be reported."""
+    import gzip
+    import numpy as np
+    from sgcount_amd import hostlib
+    rng = random.Random(99)
+    seqs = []
+    for i in range(30000):
+        n = rng.choice([0, 1, 19, 20, 21, 22, 23, 40, 51, 52, 53, 60, 90, 150, 150, 150, 400])
+        alphabet = b"ACGT" if rng.random() < 0.8 else rng.choice([b"ACGTN", b"ACGTNacgtRY", b"ACGTJ"])
+        seqs.append(bytes(rng.choice(alphabet) for _ in range(n)))
+    seqs.append(b"ACGT" * 40_000)                                   # a line much longer than a chunk's text
+    def fastq(eol, final_newline=True, blank_tail=0):
+        out = []
+        for i, s in enumerate(seqs):
+            q = bytes(rng.choice(b"@+I#5") for _ in range(len(s)))
+            out.append(b"@r%d" % i + eol + s + eol + b"+" + eol + q + eol)
+        t = b"".join(out)
+        if not final_newline:
+            t = t[: -len(eol)]
+        return t + b"\n" * blank_tail
+    p = tmp_path / "r.fastq.gz"
+    for eol, final_nl, tail, members, level in ((b"\n", True, 0, 1, 6), (b"\n", False, 0, 3, 1), (b"\r\n", True, 0, 1, 9), (b"\n", True, 3, 2, 6)):
+        text = fastq(eol, final_nl, tail)
+        cuts = sorted(rng.randrange(len(text)) for _ in range(members - 1))
+        parts = [text[a:b] for a, b in zip([0] + cuts, cuts + [len(text)])]
+        p.write_bytes(b"".join(gzip.compress(x, compresslevel=level) for x in parts))
+        for L, rev, o, rec in ((20, False, 30, True), (20, True, 30, True), (24, True, 7, True), (4, False, 2, True)):
+            want = _pack_host(seqs, L, rev, o, rec)
+            for threads, block in ((2, 1 << 22), (3, 4096), (5, 1 << 16), (4, 700)):
+                got, lines = hostlib.scan_records(str(p), L, rev, o, rec, threads=threads, block_bytes=block, cap=len(seqs) + 16)
+                assert lines == 4 * len(seqs), (eol, final_nl, tail, members, threads, block)
+                assert got.shape == want.shape and np.array_equal(got, want), (eol, final_nl, tail, members, L, rev, o, rec, threads, block)
+    # not FASTQ inside: declined (the record reader decides); one thread: declined (the sequential inflater serves it)
+    (tmp_path / "lib.fa.gz").write_bytes(gzip.compress(b">a\nACGT\n" * 50))
+    assert hostlib.scan_records(str(tmp_path / "lib.fa.gz"), 4, threads=3) is None
+    assert hostlib.scan_records(str(p), 20, threads=1, cap=len(seqs) + 16) is None
+    # a damaged stream, a truncated stream, a malformed record and a truncated record inside a good stream
+    good = gzip.compress(fastq(b"\n"), compresslevel=6)
+    bad = bytearray(good); bad[len(bad) // 2] ^= 0x55
+    (tmp_path / "bad.gz").write_bytes(bytes(bad))
+    with pytest.raises(hostlib.HostError):
+        hostlib.scan_records(str(tmp_path / "bad.gz"), 20, threads=3, block_bytes=1 << 16, cap=len(seqs) + 16)
+    (tmp_path / "trunc.gz").write_bytes(good[: len(good) * 2 // 3])
+    with pytest.raises(hostlib.HostError):
+        hostlib.scan_records(str(tmp_path / "trunc.gz"), 20, threads=3, block_bytes=1 << 16, cap=len(seqs) + 16)
+    lines = fastq(b"\n").split(b"\n")
+    mal = list(lines); mal[4 * 700 + 2] = b"-"
+    (tmp_path / "mal.gz").write_bytes(gzip.compress(b"\n".join(mal)))
+    with pytest.raises(hostlib.HostError) as e:
+        hostlib.scan_records(str(tmp_path / "mal.gz"), 20, threads=3, block_bytes=8192, cap=len(seqs) + 16)
+    assert e.value.code == 101 and "line %d " % (4 * 700 + 3) in str(e.value)
+    (tmp_path / "short.gz").write_bytes(gzip.compress(b"\n".join(lines[: 4 * 900 + 2]) + b"\n"))
+    with pytest.raises(hostlib.HostError) as e:
+        hostlib.scan_records(str(tmp_path / "short.gz"), 20, threads=2, block_bytes=8192, cap=len(seqs) + 16)
+    assert e.value.code == 101 and "truncated" in str(e.value)
+
+
 def test_bgzf_followed_by_plain_gzip_members_is_read_as_gzip(tmp_path):
     """bgzip output concatenated with ordinary gzip output is legal multi-member gzip (zlib and the reference's flate2 read
     it): the member chain is checked when the file is opened and such a file takes the sequential inflater instead of

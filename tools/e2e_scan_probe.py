@@ -40,7 +40,7 @@ def main():
                 s0 = st["samples"][0]
                 print("%-40s wall %.3f  start %.3f lib %.3f init %.3f tables %.3f sample %.3f (wait_text %.3f busy/thr %.3f thr %d copy %.3f) free %.3f exit %.3f  %s" % (
                     cfg or "(default)", wall, st["process_start_to_count_s"], st["library_load_s"], st["device_init_s"],
-                    st["table_build_s"] - st["device_init_s"], s0["wall_s"], s0["wait_for_text_s"], s0["read_busy_s"] / max(s0["reader_threads"], 1),
+                    st["table_build_s"], s0["wall_s"], s0["wait_for_text_s"], s0["read_busy_s"] / max(s0["reader_threads"], 1),
                     s0["reader_threads"], s0["host_copy_s"], st["context_free_s"], st["teardown_s"], "same table" if tab == ref else "TABLE DIFFERS"), flush=True)
     finally:
         shutil.rmtree(d, ignore_errors=True)
