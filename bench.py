@@ -56,7 +56,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-oracle budget; 0 disables the baseline")
     ap.add_argument("--variant", type=int, default=None, help="count-kernel variant (tuning)")
     ap.add_argument("--e2e-reads", type=int, default=100_000_000, help="reads of the end-to-end FASTQ leg; 0 disables it")
-    ap.add_argument("--e2e-gz-reads", type=int, default=10_000_000, help="reads of the .gz end-to-end leg; 0 disables it")
+    ap.add_argument("--e2e-gz-reads", type=int, default=30_000_000, help="reads of the .gz end-to-end leg; 0 disables it")
     ap.add_argument("--e2e-dir", default=None, help="where the FASTQ text is written (default: /dev/shm or /tmp)")
     ap.add_argument("--dominant", type=int, default=40, help="percent of the reads of the skewed-sample leg that draw ONE guide; 0 disables the leg")
     ap.add_argument("--placement-trials", type=int, default=1, help="0: skip the second timed region that prices the opt-in placement trials (profiling runs)")
@@ -452,8 +452,8 @@ def e2e_block(wl, args, exact, cpu):
                                              hybrid_vs_acgt_sample_time=legs["acgt"]["default"]["sample_s"] / legs["hybrid_100_N_guides"]["default"]["sample_s"],
                                              bytes_vs_acgt_gpu_parsed_text=legs["bytes_60pct_N_guides"]["gpu_parsed_text"]["reads_per_s"] / legs["acgt"]["gpu_parsed_text"]["reads_per_s"],
                                              note="default = what the command line picks (plain text: the host scan; a library of mostly non-ACGT guides: "
-                                                  "the byte-string path on GPU-parsed text); best of two runs each; the wall time of these 10M-read runs is "
-                                                  "mostly process start-up and the one-time table build")
+                                                  "the byte-string path on GPU-parsed text); best of two runs each; the wall time of these runs is partly "
+                                                  "process start-up and the one-time table build")
     finally:
         shutil.rmtree(d, ignore_errors=True)
     return out

@@ -436,7 +436,7 @@ TextFeeder::TextFeeder(const std::string &path_, size_t slice_bytes, size_t ring
         n_slices_known = (size_t)-1;
         threads = std::max(threads, inflate_threads);
         slice_bytes = std::min<size_t>(slice_bytes, 32u << 20);
-        if (!pgz_chunk_bytes) pgz_chunk_bytes = std::min<size_t>(std::max<size_t>(file_size / (threads * 4), 1u << 20), 8u << 20);
+        if (!pgz_chunk_bytes) pgz_chunk_bytes = (size_t)1 << 20;        // (larger chunks cost more in buffers than they save in searches: sgh_scan.cpp)
         pgz_chunks = (file_size + pgz_chunk_bytes - 1) / pgz_chunk_bytes;
         pgz_pieces.resize(pgz_chunks);
         pgz_window.assign(32768, 0);

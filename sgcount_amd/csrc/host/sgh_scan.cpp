@@ -194,9 +194,11 @@ FastqScanner::FastqScanner(const std::string &path_, const ScanParams &prm_, siz
         const bool bgzf = (map[3] & 4) && map[10] + 256u * map[11] >= 6 && map[12] == 'B' && map[13] == 'C' && map[14] == 2 && map[15] == 0;
         if (bgzf) { usable = false; return; }
         gz_mode = true;
-        // compressed bytes per chunk: from the file size; a block size below 1 MiB is taken literally (tests: many chunks of a small file)
-        gz_chunk_bytes = block_bytes < (1u << 20) ? std::max<size_t>(block_bytes, 512)
-                                                  : std::min<size_t>(std::max<size_t>(file_size / (threads * 4), 1u << 20), 8u << 20);
+        // compressed bytes per chunk: 1 MiB (a block size below that is taken literally: tests).  The chunk's symbols (2 bytes per byte
+        // of text) and text live in buffers of the worker: with 8 MiB chunks of text that compresses 19:1 those were 460 MB per
+        // thread, and a 30M-read sample took 2.2 s instead of 1.0 (tools/gz_chunk_probe.py: 8 MiB 2.1-2.4 s, 4 MiB 1.5, 2 MiB 1.1,
+        // 1 MiB 0.97-1.06, 512 KiB 1.01-1.06, 256 KiB 1.33, 128 KiB 2.0 — below, the search for a block start in every chunk weighs in)
+        gz_chunk_bytes = block_bytes < (1u << 20) ? std::max<size_t>(block_bytes, 512) : (size_t)1 << 20;
         n_blocks = (file_size + gz_chunk_bytes - 1) / gz_chunk_bytes;
         blocks.reset(new Block[n_blocks]);
         gz_pieces.resize(n_blocks);
