@@ -182,7 +182,7 @@ int sgh_scan_records(const char *path, uint32_t L, int reverse, uint32_t offset,
         uint64_t total = 0;
         while (sc.next(r, n)) {
             if (total + n > cap) throw sgh::Error("sgh_scan_records: output buffer too small");
-            memcpy(out + total * sc.words, r, n * sc.words * 8);
+            if (n) memcpy(out + total * sc.words, r, n * sc.words * 8);
             total += n;
             sc.release();
         }

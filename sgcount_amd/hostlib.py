@@ -23,7 +23,8 @@ def load():
         _ffi.load()                      # libsgcount_hip.so first (shared HIP runtime, DT_NEEDED of the host lib)
         if _build._host_needs_build(_build.HOST_SO) or _build._host_needs_build(_build.CLI):
             _build.build_host()
-        L = C.CDLL(_build.HOST_SO)
+        # SGH_HOST_LIB: another build of the host library to load instead (the AddressSanitizer build of tools/asan_host_tests.sh)
+        L = C.CDLL(os.environ.get("SGH_HOST_LIB") or _build.HOST_SO)
         L.sgh_last_error.restype = C.c_char_p
         for name in ("sgh_cli", "sgh_entropy_offset_group", "sgh_positional_entropy", "sgh_minimize_mse",
                      "sgh_generate_sample_names", "sgh_genemap_get", "sgh_genemap_missing", "sgh_generate_columns",
