@@ -411,7 +411,9 @@ def e2e_block(wl, args, exact, cpu):
                            "table_equals_resident_pass": bool(np.array_equal(got, want_gz)) and int(smp["reads"]) == total_gz,
                            "sample_s": smp["wall_s"], "inflate_busy_s_sum_over_threads": smp["read_busy_s"],
                            "reader_threads": smp["reader_threads"], "prepare_s": prep,
-                           "note": "BGZF members are independent deflate streams: inflated in parallel straight into the pinned slices"}
+                           "stages": stages_of(stats),
+                           "note": "BGZF members are independent deflate streams: runs of whole members are inflated (zlib) and packed into records by the "
+                                   "scanner's threads, beside the device's start-up like plain gzip; --pack fastq inflates them into pinned slices for the GPU parser"}
             if cpu and "cpu_port_reads_per_s" in out.get("gz", {}):
                 out["bgzf"]["speedup_vs_cpu"] = out["bgzf"]["reads_per_s"] / out["gz"]["cpu_port_reads_per_s"]
             # libraries with guides outside ACGT (upstream compares raw bytes: library.rs:89-99): the same text against the same

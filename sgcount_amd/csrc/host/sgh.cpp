@@ -1102,7 +1102,7 @@ static void count_fastq_scan(sgc_sample *smp, FastqScanner &scan, SampleStats *s
     sgc_check(sgc_sample_wait_uploads(smp, 0), "sgc_sample_wait_uploads");         // the ring is freed on return
     if (st) {
         st->text_bytes = scan.gz_mode ? 0 : scan.file_size; st->reader_threads = scan.n_threads;
-        st->gz = scan.gz_mode; st->pgz = scan.gz_mode; st->pgz_fallbacks = scan.pgz_fallbacks;
+        st->gz = scan.gz_mode; st->bgzf = scan.bgzf_mode; st->pgz = scan.gz_mode && !scan.bgzf_mode; st->pgz_fallbacks = scan.pgz_fallbacks;
         st->read_busy_s = scan.busy_s; st->read_wait_s = scan.wait_s; st->push_s = t_push; st->upload_wait_s = t_upwait;
         st->feeder_setup_s = t_a1 - t_a0; st->host_copy_s = t_copy; st->scan_path = true; st->scan_mapped = scan.used_mapping();
     }

@@ -235,6 +235,8 @@ class FastqScanner {
     // does), resolved into a buffer of the thread's own, and packed there — no text leaves the thread, and nothing needs the device,
     // so a .gz sample inflates while the device starts up and the tables are built
     bool gz_mode = false;
+    bool bgzf_mode = false;             // gz_mode, and every member announces its size (BGZF): members are independent streams, a chunk
+                                        // is a run of whole members, inflated by zlib straight into text (no speculation, no window chain)
     size_t pgz_fallbacks = 0;           // chunks decoded in order after all (speculation failed)
     size_t file_size = 0, n_threads = 0, words = 1;
     uint64_t total_lines = 0;           // after next() returned false
@@ -253,6 +255,7 @@ class FastqScanner {
     bool gz_eos = false, gz_first_known = false, gz_verified = false, gz_text_ends_nl = false;
     uint8_t gz_first_byte = 0;
     std::vector<uint8_t> gz_window, gz_carry;
+    std::vector<size_t> bgzf_chunk_off;         // BGZF: file offset of the first member of every chunk (+ the end of the file)
     struct GzPiece { uint32_t crc; uint64_t len; bool member_end; uint32_t want_crc, want_isize; };
     std::vector<std::vector<GzPiece>> gz_pieces;
     static constexpr size_t READ_SLACK = 64u << 10;      // bytes read behind a block: the rest of its last line, and the window loads

@@ -191,8 +191,6 @@ FastqScanner::FastqScanner(const std::string &path_, const ScanParams &prm_, siz
     if (file_size >= 64 && map[0] == 0x1f && map[1] == 0x8b && map[2] == 8 && threads > 1) {
         // gzip.  BGZF (members that announce their size: independent streams) is left to the reader that inflates members in parallel
         // straight into pinned memory; a plain stream is decoded here, chunk by chunk
-        const bool bgzf = (map[3] & 4) && map[10] + 256u * map[11] >= 6 && map[12] == 'B' && map[13] == 'C' && map[14] == 2 && map[15] == 0;
-        if (bgzf) { usable = false; return; }
         gz_mode = true;
         // compressed bytes per chunk: 1 MiB (a block size below that is taken literally: tests).  The chunk's symbols (2 bytes per byte
         // of text) and text live in buffers of the worker: with 8 MiB chunks of text that compresses 19:1 those were 460 MB per
@@ -200,6 +198,32 @@ FastqScanner::FastqScanner(const std::string &path_, const ScanParams &prm_, siz
         // 1 MiB 0.97-1.06, 512 KiB 1.01-1.06, 256 KiB 1.33, 128 KiB 2.0 — below, the search for a block start in every chunk weighs in)
         gz_chunk_bytes = block_bytes < (1u << 20) ? std::max<size_t>(block_bytes, 512) : (size_t)1 << 20;
         n_blocks = (file_size + gz_chunk_bytes - 1) / gz_chunk_bytes;
+        // BGZF (bgzip, htslib, Illumina's converters)?  Only if EVERY member announces its size in a 'BC' extra subfield — bgzip output
+        // followed by ordinary gzip output is legal gzip and takes the plain-stream decoder: hop through the member headers once
+        // and cut the file into runs of whole members of about a chunk each
+        {
+            size_t off = 0, chunk_start = 0;
+            bool chain = true;
+            std::vector<size_t> cuts(1, 0);
+            while (chain && off < file_size) {
+                const uint8_t *h = map + off;
+                if (file_size - off < 28 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { chain = false; break; }
+                const size_t xlen = h[10] + 256u * h[11];
+                if (12 + xlen + 8 > file_size - off) { chain = false; break; }
+                size_t bsize = 0;
+                for (size_t x = 12; x + 4 <= 12 + xlen;) {
+                    const size_t slen = h[x + 2] + 256u * h[x + 3];
+                    if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2 && x + 6 <= 12 + xlen) bsize = (size_t)(h[x + 4] + 256u * h[x + 5]) + 1;
+                    x += 4 + slen;
+                }
+                if (bsize < 12 + xlen + 8 || bsize > file_size - off) chain = false;
+                else {
+                    off += bsize;
+                    if (off - chunk_start >= gz_chunk_bytes && off < file_size) { cuts.push_back(off); chunk_start = off; }
+                }
+            }
+            if (chain) { bgzf_mode = true; cuts.push_back(file_size); bgzf_chunk_off.swap(cuts); n_blocks = bgzf_chunk_off.size() - 1; }
+        }
         blocks.reset(new Block[n_blocks]);
         gz_pieces.resize(n_blocks);
         gz_window.assign(32768, 0);
@@ -334,12 +358,63 @@ void FastqScanner::run_gz() {
             size_t k;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return stop || failed || gz_next >= n_blocks || gz_next < gz_chain + 2 * n_threads; });
+                // (not too far ahead of the chain that stitches the chunks: decoded chunks wait in memory)
+                cv.wait(lk, [&] { return stop || failed || gz_next >= n_blocks || gz_next < (bgzf_mode ? gz_lines : gz_chain) + 2 * n_threads; });
                 if (stop || failed || gz_next >= n_blocks) return;
                 k = gz_next++;
             }
             const double t0 = scan_now_s();
             Block &blk = blocks[k];
+            static thread_local std::vector<uint8_t> text_keep, lut_keep;
+            constexpr size_t ROOM = 1u << 16;           // in front of the chunk's text: room for the unfinished line it continues
+            uint8_t *txt = nullptr;
+            size_t n = 0;
+            bool last = false;
+            std::vector<GzPiece> pieces;
+            if (bgzf_mode) {
+                // the members [bgzf_chunk_off[k], bgzf_chunk_off[k + 1]): sizes from the ISIZE trailers, then zlib, member by member
+                const size_t c_lo = bgzf_chunk_off[k], c_hi = bgzf_chunk_off[k + 1];
+                auto bsize_of = [&](size_t off, size_t &xlen) {
+                    const uint8_t *h = map + off;
+                    xlen = h[10] + 256u * h[11];
+                    size_t bsize = 0;
+                    for (size_t x = 12; x + 4 <= 12 + xlen;) {
+                        const size_t slen = h[x + 2] + 256u * h[x + 3];
+                        if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) bsize = (size_t)(h[x + 4] + 256u * h[x + 5]) + 1;
+                        x += 4 + slen;
+                    }
+                    return bsize;
+                };
+                size_t total = 0;
+                for (size_t off = c_lo; off < c_hi;) {
+                    size_t xlen; const size_t bs = bsize_of(off, xlen);
+                    const uint8_t *tr = map + off + bs - 8;
+                    total += (size_t)tr[4] | (size_t)tr[5] << 8 | (size_t)tr[6] << 16 | (size_t)tr[7] << 24;
+                    off += bs;
+                }
+                if (text_keep.size() < ROOM + total + 64) text_keep.resize(ROOM + total + 64 + (total >> 3));
+                txt = text_keep.data() + ROOM;
+                static thread_local z_stream zs;
+                static thread_local bool zs_ready = false;
+                if (!zs_ready) { memset(&zs, 0, sizeof zs); if (inflateInit2(&zs, -15) != Z_OK) throw Error("zlib: inflateInit2 failed"); zs_ready = true; }
+                size_t at = 0;
+                for (size_t off = c_lo; off < c_hi;) {
+                    size_t xlen; const size_t bs = bsize_of(off, xlen);
+                    const uint8_t *tr = map + off + bs - 8;
+                    const uint32_t want_crc = (uint32_t)tr[0] | (uint32_t)tr[1] << 8 | (uint32_t)tr[2] << 16 | (uint32_t)tr[3] << 24;
+                    const size_t isize = (size_t)tr[4] | (size_t)tr[5] << 8 | (size_t)tr[6] << 16 | (size_t)tr[7] << 24;
+                    if (inflateReset2(&zs, -15) != Z_OK) throw Error("zlib: inflateReset2 failed");
+                    zs.next_in = const_cast<Bytef *>(map + off + 12 + xlen); zs.avail_in = (uInt)(bs - 12 - xlen - 8);
+                    zs.next_out = txt + at; zs.avail_out = (uInt)isize;
+                    const int rc = inflate(&zs, Z_FINISH);
+                    if (rc != Z_STREAM_END || zs.avail_out != 0 || crc32_fast(0, txt + at, isize) != want_crc)
+                        throw Error("corrupt BGZF member in " + path);
+                    at += isize; off += bs;
+                }
+                n = total;
+                memset(txt + n, 0, 64);
+                last = k + 1 == n_blocks;
+            } else {
             const size_t lo = k * gz_chunk_bytes, hi = std::min(file_size, lo + gz_chunk_bytes);
             const size_t max_out = (size_t)1 << 31;
             static thread_local std::vector<uint16_t> sym_keep;     // kept from chunk to chunk: fresh pages cost more than decoding
@@ -365,7 +440,7 @@ void FastqScanner::run_gz() {
             if (found && inflate_span(map, file_size, start, 8ull * hi, nullptr, span, max_out) != 0) { found = false; reset_span(); }
             // ---- chain A: the chunk's true start and the window in front of it
             uint8_t window[32768];
-            bool empty = false, last = false;
+            bool empty = false;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return stop || failed || gz_chain == k; });
@@ -401,16 +476,13 @@ void FastqScanner::run_gz() {
             }
             cv.notify_all();
             // ---- the text of the chunk, behind room for the unfinished line in front of it; CRC-32 of every member piece
-            const size_t n = span.sym.size();
-            static thread_local std::vector<uint8_t> text_keep, lut_keep;
-            constexpr size_t ROOM = 1u << 16;
+            n = span.sym.size();
             if (text_keep.size() < ROOM + n + 64) text_keep.resize(ROOM + n + 64 + (n >> 3));
-            uint8_t *txt = text_keep.data() + ROOM;
+            txt = text_keep.data() + ROOM;
             if (lut_keep.size() != 65536) { lut_keep.assign(65536, 0); for (unsigned i = 0; i < 256; i++) lut_keep[i] = (uint8_t)i; }
             memcpy(lut_keep.data() + 0x8000, window, 32768);
             resolve_symbols(span.sym.data(), n, lut_keep.data(), txt);
             memset(txt + n, 0, 64);
-            std::vector<GzPiece> pieces;
             {
                 size_t done = 0, mi = 0;
                 uint32_t crc = 0;
@@ -427,6 +499,7 @@ void FastqScanner::run_gz() {
                 }
                 if (piece_len) pieces.push_back(GzPiece{crc, piece_len, false, 0, 0});
             }
+            }       // plain gzip stream
             // line starts behind every newline of the chunk (relative to txt; one at n belongs to the next chunk)
             std::vector<uint32_t> nls;
             nls.reserve(n / 64 + 16);

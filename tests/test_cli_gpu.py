@@ -203,11 +203,16 @@ def test_bgzf_input_is_inflated_in_parallel(cli, tmp_path, example_library_text,
     p = os.path.join(str(tmp_path), "diff.fastq.gz")
     open(p, "wb").write(bgzf_bytes(text, block=20000))
     stats = os.path.join(str(tmp_path), "stats.json")
-    rc, out, err = run(cli, "-l", LIB, "-i", p, "-a", "5", "-q", "--io-threads", "4", "--chunk-mb", "0", "--stats-json", stats)
-    assert rc == 0, err
-    assert out == oracle_table(example_library_text, [text], ["diff"], [(False, 5)], False, True)
-    s0 = json.load(open(stats))["samples"][0]
-    assert s0["text_path"] and s0["gz"] and s0["bgzf"] and s0["reads"] == 1101 * 40 and s0["reader_threads"] == 4
+    # default: the host scan inflates the members and packs (sgh_scan.cpp run_gz); --pack fastq: the text path inflates them into
+    # pinned slices and the GPU parses
+    for pack, key in (("scan", "scan_path"), ("fastq", "text_path")):
+        rc, out, err = run(cli, "-l", LIB, "-i", p, "-a", "5", "-q", "--io-threads", "4", "--scan-threads", "4", "--chunk-mb", "0", "--pack", pack,
+                           "--stats-json", stats)
+        assert rc == 0, err
+        assert out == oracle_table(example_library_text, [text], ["diff"], [(False, 5)], False, True)
+        s0 = json.load(open(stats))["samples"][0]
+        assert s0[key] and s0["gz"] and s0["bgzf"] and s0["reads"] == 1101 * 40, (pack, s0)
+        assert s0["reader_threads"] == 4 if pack == "fastq" else 1 <= s0["reader_threads"] <= 4      # (the scanner: as many as the file has chunks)
     # a corrupt member is an error, not a silent miscount
     blob = bytearray(open(p, "rb").read())
     blob[len(blob) // 2] ^= 0x55

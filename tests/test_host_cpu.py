@@ -350,6 +350,21 @@ def test_scanner_packs_a_gzip_stream_like_its_text(tmp_path):
                 got, lines = hostlib.scan_records(str(p), L, rev, o, rec, threads=threads, block_bytes=block, cap=len(seqs) + 16)
                 assert lines == 4 * len(seqs), (eol, final_nl, tail, members, threads, block)
                 assert got.shape == want.shape and np.array_equal(got, want), (eol, final_nl, tail, members, L, rev, o, rec, threads, block)
+    # BGZF (every member announces its size): runs of whole members, inflated by zlib in the workers; BGZF followed by a plain gzip
+    # member is not BGZF throughout and takes the speculative decoder; a damaged member is reported
+    from sgcount_amd.bgzf import bgzf_bytes
+    text = fastq(b"\n")
+    want = _pack_host(seqs, 20, False, 30, True)
+    for name, blob in (("b1.gz", bgzf_bytes(text, 65280)), ("b2.gz", bgzf_bytes(text, 12000, eof_marker=False)),
+                       ("b3.gz", bgzf_bytes(text[: len(text) // 2], 20000, eof_marker=False) + gzip.compress(text[len(text) // 2:]))):
+        (tmp_path / name).write_bytes(blob)
+        for threads, block in ((2, 1 << 22), (4, 1 << 16), (3, 5000)):
+            got, lines = hostlib.scan_records(str(tmp_path / name), 20, False, 30, True, threads=threads, block_bytes=block, cap=len(seqs) + 16)
+            assert lines == 4 * len(seqs) and np.array_equal(got, want), (name, threads, block)
+    blob = bytearray(bgzf_bytes(text, 30000)); blob[len(blob) // 2] ^= 0x10
+    (tmp_path / "bbad.gz").write_bytes(bytes(blob))
+    with pytest.raises(hostlib.HostError):
+        hostlib.scan_records(str(tmp_path / "bbad.gz"), 20, False, 30, True, threads=3, block_bytes=1 << 16, cap=len(seqs) + 16)
     # not FASTQ inside: declined (the record reader decides); one thread: declined (the sequential inflater serves it)
     (tmp_path / "lib.fa.gz").write_bytes(gzip.compress(b">a\nACGT\n" * 50))
     assert hostlib.scan_records(str(tmp_path / "lib.fa.gz"), 4, threads=3) is None
