@@ -163,6 +163,13 @@ int sgc_sample_push_packed_async(sgc_sample *, const void *records, uint64_t n);
 
 /* Same, from raw read bytes: the device packs (pack kernel) then counts. */
 int sgc_sample_push_reads(sgc_sample *, const uint8_t *seqs, const uint64_t *offsets, uint64_t n, int where);
+/* The same for reads of which only the bytes that matter are shipped: entry i is the piece of read i that holds its windows — in
+ * the read's orientation, bases [max(o - 1, 0), min(len, o + L + 1)) (o: the sample's offset; for a reverse-strand sample that is
+ * the tail of the line as it stands in the file) — and window_offset is o seen from the start of that piece (1, or 0 when o is 0).
+ * Every decision of Counter::assign (src/counter.rs:96-180) depends on the read only through those bytes and through whether the
+ * windows fit, which the piece preserves; the C++ scanner ships the reads it routes to the byte-string chain of a hybrid library
+ * this way: L + 2 bytes instead of the read. */
+int sgc_sample_push_windows(sgc_sample *, const uint8_t *pieces, const uint64_t *offsets, uint64_t n, int where, uint32_t window_offset);
 
 /* Same, from a chunk of FASTQ text holding whole 4-line records: the device finds the record
  * boundaries, packs and counts.  n_records_out may be NULL.  Waits for the device's line count (one stream

@@ -49,6 +49,7 @@ SYMBOLS = {
     "sgc_sample_push_packed": (_i, [_vp, _vp, _u64, _i]),
     "sgc_sample_push_packed_async": (_i, [_vp, _vp, _u64]),
     "sgc_sample_push_reads": (_i, [_vp, _u8p, _vp, _u64, _i]),
+    "sgc_sample_push_windows": (_i, [_vp, _u8p, _vp, _u64, _i, C.c_uint32]),
     "sgc_sample_push_fastq": (_i, [_vp, _u8p, _u64, _i, C.POINTER(_u64)]),
     "sgc_sample_push_fastq_part": (_i, [_vp, _u8p, _u64, _i, _u64, _u64, C.POINTER(_u64)]),
     "sgc_sample_wait_uploads": (_i, [_vp, _u32]),

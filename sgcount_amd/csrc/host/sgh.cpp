@@ -1073,7 +1073,7 @@ static void count_fastq_scan(sgc_sample *smp, FastqScanner &scan, SampleStats *s
         const uint64_t nr = roffs.size() - 1;
         if (!nr) return;
         const double t0 = now_s();
-        sgc_check(sgc_sample_push_reads(smp, rbytes.data(), roffs.data(), nr, SGC_MEM_HOST), "sgc_sample_push_reads");
+        sgc_check(sgc_sample_push_windows(smp, rbytes.data(), roffs.data(), nr, SGC_MEM_HOST, scan.window_offset()), "sgc_sample_push_windows");
         sgc_check(sgc_sample_sync(smp), "sgc_sample_sync");            // the vectors are reused
         t_push += now_s() - t0;
         rbytes.clear(); roffs.resize(1);

@@ -227,8 +227,8 @@ class FastqScanner {
     // Panic on a malformed record (wrong marker byte; a line count that is no multiple of 4 at the end).
     bool next(const uint64_t *&recs, size_t &n_records);
     void release();                     // the block returned by the last next() may be dropped
-    // the reads of the block returned by the last next() that were set aside (ScanParams::route): n_routed reads, read i =
-    // routed_bytes[routed_offs[i], routed_offs[i + 1])
+    // the reads of the block returned by the last next() that were set aside (ScanParams::route): n_routed reads, of read i the piece
+    // that holds its windows = routed_bytes[routed_offs[i], routed_offs[i + 1]) (window_offset(): the sample's offset inside a piece)
     const uint8_t *routed_bytes = nullptr; const uint64_t *routed_offs = nullptr; size_t n_routed = 0;
     bool usable = true;
     // the file is ONE gzip stream (not BGZF): its chunks are decoded speculatively by the workers (sgh_inflate.cpp, as TextFeeder::run_pgz
@@ -265,6 +265,7 @@ class FastqScanner {
   public:
     bool used_mapping() const { return source == 1 || auto_map.load(); }
     bool routes() const { return prm.route != nullptr; }
+    uint32_t window_offset() const { return prm.offset >= 1 ? 1u : 0u; }      // of the pieces in routed_bytes (sgc_sample_push_windows)
   private:
     std::string path;
     ScanParams prm;

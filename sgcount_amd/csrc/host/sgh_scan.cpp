@@ -641,8 +641,11 @@ void FastqScanner::extract(Block &blk, const uint8_t *t, size_t lo, size_t t_hi,
                 }
             }
             if (route) {
+                // only the piece of the read that holds its windows (sgc_sample_push_windows): oriented bases [max(o - 1, 0), min(n, o + L + 1))
+                const size_t lo_or = o >= 1 ? (size_t)o - 1 : 0, hi_or = std::min<size_t>(n, (size_t)o + L + 1);
+                const size_t plen = hi_or > lo_or ? hi_or - lo_or : 0, pbeg = plen ? (rev ? n - hi_or : lo_or) : 0;
                 if (blk.routed_offs.empty()) blk.routed_offs.push_back(0);
-                blk.routed_bytes.insert(blk.routed_bytes.end(), src + s, src + s + n);
+                blk.routed_bytes.insert(blk.routed_bytes.end(), src + s + pbeg, src + s + pbeg + plen);
                 blk.routed_offs.push_back(blk.routed_bytes.size());
                 continue;
             }

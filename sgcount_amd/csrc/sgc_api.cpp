@@ -1321,6 +1321,17 @@ int sgc_sample_push_reads(sgc_sample *s, const uint8_t *seqs, const uint64_t *of
     return count_records(s, c->d_recs, n);
 }
 
+int sgc_sample_push_windows(sgc_sample *s, const uint8_t *pieces, const uint64_t *offsets, uint64_t n, int where, uint32_t window_offset) {
+    if (!s) return fail(SGC_E_ARG, "sgc_sample_push_windows: NULL argument");
+    if (window_offset > 1 || window_offset > s->offset) return fail(SGC_E_ARG, "sgc_sample_push_windows: window_offset is 1, or 0 for a sample with offset 0");
+    // (every launch below takes the offset by value: the sample's own is back before anything else can look at it)
+    const auto keep = s->offset;
+    s->offset = window_offset;
+    const int rc = sgc_sample_push_reads(s, pieces, offsets, n, where);
+    s->offset = keep;
+    return rc;
+}
+
 // One part of a FASTQ stream: whole lines, starting at global line number first_line (any phase of the 4-line
 // cycle).  n_newlines == UINT64_MAX: unknown — the device counts and the call waits for the count.
 static int push_fastq_part(sgc_sample *s, const uint8_t *text, uint64_t n_bytes, int where, uint64_t first_line,

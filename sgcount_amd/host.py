@@ -280,8 +280,8 @@ class Counter:
     def new(cls, reader, library: Library, permuter, offset: Offset, size: int, position_recursion: bool,
             pack: str = "host", batch: int = 1 << 20, device_index: int = 0, options=None):
         """Counter::new (src/counter.rs:36-66): consumes `reader`, returns the finished Counter.
-        pack = "host" (sgc_pack_reads_host, the north-star split), "device" (pack kernel) or "fastq" (the reads as FASTQ
-        text through sgc_sample_push_fastq).  A library without a packed record format (non-ACGT bytes, L > 30) is
+        pack = "host" (sgc_pack_reads_host, the north-star split), "device" (pack kernel), "windows" (the pack kernel on the
+        pieces of the reads that hold their windows) or "fastq" (the reads as FASTQ text through sgc_sample_push_fastq).  A library without a packed record format (non-ACGT bytes, L > 30) is
         served from the read bytes whatever `pack` says — on the device either way."""
         if size != library.size():
             raise ValueError("size must equal library.size() (src/count.rs:31)")
@@ -304,11 +304,21 @@ class Counter:
                 elif pack == "device":
                     flat, offs = _flatten(chunk)
                     _ffi.check(lib.sgc_sample_push_reads(sample, flat, offs.ctypes.data, len(chunk), _ffi.MEM_HOST))
+                elif pack == "windows":
+                    # of every read only the piece that holds its windows (sgc_sample_push_windows), as the C++ scanner ships the
+                    # reads it routes to the byte-string chain: oriented bases [max(o - 1, 0), min(len, o + L + 1))
+                    o, rev = offset.index(), offset.is_reverse()
+                    pieces = []
+                    for r in chunk:
+                        lo, hi = max(o - 1, 0), min(len(r), o + size + 1)
+                        pieces.append(b"" if hi <= lo else (r[len(r) - hi: len(r) - lo] if rev else r[lo:hi]))
+                    flat, offs = _flatten(pieces)
+                    _ffi.check(lib.sgc_sample_push_windows(sample, flat, offs.ctypes.data, len(pieces), _ffi.MEM_HOST, 1 if o >= 1 else 0))
                 elif pack == "fastq":
                     text = b"".join(b"@r\n%s\n+\n%s\n" % (r, b"I" * len(r)) for r in chunk)
                     _ffi.check(lib.sgc_sample_push_fastq(sample, text, len(text), _ffi.MEM_HOST, None))
                 else:
-                    raise ValueError("pack must be 'host', 'device' or 'fastq'")
+                    raise ValueError("pack must be 'host', 'device', 'windows' or 'fastq'")
                 _ffi.check(lib.sgc_sample_sync(sample))
                 chunk.clear()
 

@@ -292,7 +292,7 @@ def test_hybrid_library_vs_oracle(S, L, n_guides, frac, reverse):
     for exact in (False, True):
         for recursion in (True, False):
             want, tot, mat = O.count_text(lib_text, reads_text, reverse, o, exact, recursion)
-            for pack in ("device", "fastq"):
+            for pack in ("device", "fastq", "windows"):
                 rs = [r for r in S.parse_fastx(reads_text)]
                 ctr = S.Counter.new(iter(rs), lib, None if exact else perm, off, L, recursion, pack=pack, batch=4001)
                 assert ctr.guide_counts().tolist() == want, (exact, recursion, pack)

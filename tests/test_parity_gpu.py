@@ -197,6 +197,30 @@ def _random_case(rng, L, n_guides, n_reads, o):
     return guides, reads
 
 
+@pytest.mark.parametrize("o", [0, 1, 2, 31])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_window_pieces_count_like_whole_reads(S, o, reverse):
+    """sgc_sample_push_windows: of every read only the piece that holds its windows (what the C++ scanner ships for the reads it
+    routes to the byte-string chain of a hybrid library).  Same table as the oracle on the whole reads, for offsets at and next
+    to zero, reads too short for some or all windows, both strands, with and without the position recursion."""
+    rng = random.Random(77 + o + 10 * reverse)
+    L = 20
+    guides, reads = _random_case(rng, L, 800, 12000, o)
+    reads += [b"", b"A", b"ACGT" * 3, bytes(guides[0])[: L - 1], bytes(guides[1])]
+    if reverse:
+        reads = [bytes((c ^ 4) if (c & 2) else (c ^ 21) for c in reversed(r)) for r in reads]
+    lib_text, reads_text = _fasta(guides), _reads_fasta(reads)
+    lib = _lib(S, lib_text)
+    perm = S.Permuter.new(lib.keys())
+    off = S.Offset.Reverse(o) if reverse else S.Offset.Forward(o)
+    for exact in (False, True):
+        for recursion in (True, False):
+            want, tot, mat = O.count_text(lib_text, reads_text, reverse, o, exact, recursion)
+            ctr = S.Counter.new(S.parse_fastx(reads_text), lib, None if exact else perm, off, L, recursion, pack="windows", batch=5000)
+            assert ctr.guide_counts().tolist() == want, (exact, recursion)
+            assert (ctr.total_reads(), ctr.matched_reads()) == (tot, mat)
+
+
 @pytest.mark.parametrize("variant", [4, 3])
 @pytest.mark.parametrize("L,n_guides", [(20, 2000), (12, 300), (23, 500), (27, 400)])
 @pytest.mark.parametrize("reverse", [False, True])
@@ -216,7 +240,7 @@ def test_random_vs_oracle(S, L, n_guides, reverse, variant):
         lib.device(not exact).set_option("variant", variant)
         for recursion in (True, False):
             want, tot, mat = O.count_text(lib_text, reads_text, reverse, o, exact, recursion)
-            for pack in ("host", "device"):
+            for pack in ("host", "device", "windows"):
                 ctr = S.Counter.new(S.parse_fastx(reads_text), lib, None if exact else perm, off, L, recursion,
                                     pack=pack, batch=7001)
                 assert ctr.guide_counts().tolist() == want, (exact, recursion, pack)
