@@ -14,11 +14,15 @@ import numpy as np                               # noqa: E402
 from sgcount_amd.workload import DeviceWorkload  # noqa: E402
 
 ref = None
-for n, ng, opts in ((1_000_000, 20_000, {}), (1_000_000, 20_000, {"five_byte": 0}), (1_000_000, 20_000, {"five_byte": 0, "six_byte": 0}),
-                    (1_000_000, 20_000, {"direct": 0}), (1_000_000, 20_000, {"dense": 0, "cuckoo": 0}), (1_000_000, 20_000, {"variant": 3}),
-                    (40_000_000, 100_000, {}), (40_000_000, 100_000, {"place_trials": 4}), (3_000, 300, {}), (1_500_000, 150_000, {})):
+from sgcount_amd import synth                    # noqa: E402
+DOM = synth.MODE_FIXED | synth.mode_dominant(60)  # a sample that one guide dominates: most workgroups of k_count_slices on one slice, segments
+for n, ng, opts, mode in ((1_000_000, 20_000, {}, 0), (1_000_000, 20_000, {"balanced": 0}, 0), (1_000_000, 20_000, {"five_byte": 0}, 0),
+                          (1_000_000, 20_000, {"five_byte": 0, "six_byte": 0}, 0),
+                          (1_000_000, 20_000, {"direct": 0}, 0), (1_000_000, 20_000, {"dense": 0, "cuckoo": 0}, 0), (1_000_000, 20_000, {"variant": 3}, 0),
+                          (40_000_000, 100_000, {}, 0), (40_000_000, 100_000, {"place_trials": 4}, 0), (3_000, 300, {}, 0), (1_500_000, 150_000, {}, 0),
+                          (8_000_000, 100_000, {}, DOM), (8_000_000, 100_000, {"balanced": 0}, DOM), (2_000, 100_000, {}, DOM)):
     for exact in (False, True):
-        wl = DeviceWorkload(n, ng, 20, one_mismatch=not exact, gen_chunk=2_000_000)
+        wl = DeviceWorkload(n, ng, 20, one_mismatch=not exact, gen_chunk=2_000_000, mode=mode)
         for k, v in opts.items():
             wl.dl.set_option(k, v)
         wl.step()
@@ -28,7 +32,7 @@ for n, ng, opts in ((1_000_000, 20_000, {}), (1_000_000, 20_000, {"five_byte": 0
         t, m = C.c_uint64(), C.c_uint64()
         _ffi.check(lib.sgc_sample_finish(wl.sample, out.ctypes.data, C.byref(t), C.byref(m)))       # raises on a bounds flag
         assert total == n and int(counts.sum()) == matched == m.value
-        key = (n, ng, exact)
+        key = (n, ng, exact, mode)
         if not opts:
             ref = ref or {}
             ref[key] = counts.tolist()
@@ -41,5 +45,5 @@ for n, ng, opts in ((1_000_000, 20_000, {}), (1_000_000, 20_000, {"five_byte": 0
         b = wl.result()[0]
         assert (a + b).tolist() == counts.tolist()
         wl.close()
-        print("ok", n, ng, opts, "exact" if exact else "1mm", flush=True)
+        print("ok", n, ng, opts, "dominant" if mode else "", "exact" if exact else "1mm", flush=True)
 print("CHECKED BUILD OK")
