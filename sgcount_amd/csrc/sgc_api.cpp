@@ -670,7 +670,7 @@ int sgc_ctx_clone(sgc_ctx *src, sgc_ctx **out) {
     // and the options that shape the passes
     c->variant = src->variant; c->per_lane = src->per_lane; c->k1_wgs = src->k1_wgs; c->max_chunk = src->max_chunk;
     c->batch_records = src->batch_records; c->dense = src->dense; c->direct = src->direct; c->six_byte = src->six_byte;
-    c->five_byte = src->five_byte; c->tag_sub = src->tag_sub; c->use_cuckoo = src->use_cuckoo; c->place_trials = src->place_trials;
+    c->five_byte = src->five_byte; c->balanced = src->balanced; c->tag_sub = src->tag_sub; c->use_cuckoo = src->use_cuckoo; c->place_trials = src->place_trials;
     c->verbose = src->verbose; c->host_routes = src->host_routes;
     *out = c;
     return SGC_OK;
