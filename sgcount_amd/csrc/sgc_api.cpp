@@ -1298,11 +1298,13 @@ int sgc_sample_push_reads(sgc_sample *s, const uint8_t *seqs, const uint64_t *of
         const uint64_t nbytes = offsets[n];
         int rc = ensure(&c->d_stage, &c->stage_cap, nbytes ? nbytes : 1);
         if (rc) return rc;
-        rc = ensure(&c->d_aux, &c->aux_cap, (n + 1) * 8);
+        // (the offsets live in a buffer of their own: a hybrid ctx reads them again AFTER its packed pass — the byte-string chain of
+        // the flagged reads —, and the probing resolver of that pass, variant 3, keeps its segment counts in d_aux)
+        rc = ensure(&c->d_lines, &c->lines_cap, (n + 1) * 8);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(c->d_stage, seqs, nbytes, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_aux, offsets, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
-        d_seqs = (const uint8_t *)c->d_stage; d_off = (const uint64_t *)c->d_aux;
+        HIP_TRY(hipMemcpyAsync(c->d_lines, offsets, (n + 1) * 8, hipMemcpyHostToDevice, c->stream));
+        d_seqs = (const uint8_t *)c->d_stage; d_off = (const uint64_t *)c->d_lines;
     } else if (where != SGC_MEM_DEVICE) {
         return fail(SGC_E_ARG, "sgc_sample_push_reads: where must be SGC_MEM_HOST or SGC_MEM_DEVICE");
     }

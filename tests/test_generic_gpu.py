@@ -297,6 +297,13 @@ def test_hybrid_library_vs_oracle(S, L, n_guides, frac, reverse):
                 ctr = S.Counter.new(iter(rs), lib, None if exact else perm, off, L, recursion, pack=pack, batch=4001)
                 assert ctr.guide_counts().tolist() == want, (exact, recursion, pack)
                 assert (ctr.total_reads(), ctr.matched_reads()) == (tot, mat)
+    # the probing resolver (variant 3: what a library without a core index gets) in a hybrid ctx, many small pushes: the packed pass
+    # must leave the pushed reads' offsets alone, the byte-string chain reads them after it (it kept its segment counts on them once:
+    # found by tools/fuzz_parity.py)
+    want, tot, mat = O.count_text(lib_text, reads_text, reverse, o, False, True)
+    for pack, batch in (("device", 7), ("windows", 64)):
+        ctr = S.Counter.new(S.parse_fastx(reads_text), lib, perm, off, L, True, pack=pack, batch=batch, options={"variant": 3})
+        assert ctr.guide_counts().tolist() == want and (ctr.total_reads(), ctr.matched_reads()) == (tot, mat), (pack, batch)
     # lookups go through the whole library's byte-string tables
     dl = lib.device(True)
     toks = [bytes(g) for g in guides[:50]]
