@@ -90,7 +90,18 @@ bool FastxReader::next(RecordView &r) {
         return true;
     };
     if (!get(0)) return false;
-    if (l[0] == 0 && s.pos >= s.end && s.eof) return false;     // trailing blank line
+    if (l[0] == 0) {
+        // blank lines at the very end are not records (the scanner and the text path cut them off the same way); a blank line with
+        // anything behind it is a malformed header, below
+        bool only_blank = true;
+        size_t bo, bl;
+        const size_t pos0 = s.pos;
+        size_t keep2 = keep;
+        while (only_blank && s.line(keep2, bo, bl)) only_blank = bl == 0;
+        if (only_blank) return false;
+        (void)pos0;
+        throw Panic("malformed FASTX header in " + s.path);
+    }
     if (s.fmt == 0) {
         if (l[0] && s.buf[o[0]] == '>') s.fmt = 1;
         else if (l[0] && s.buf[o[0]] == '@') s.fmt = 2;

@@ -250,7 +250,7 @@ class FastqScanner {
     void extract(Block &blk, const uint8_t *t, size_t lo, size_t t_hi, size_t n_pack, size_t text_end);
     // gz mode: the chain that stitches the chunks (A: deflate position and window; B: line numbers and the unfinished line)
     static constexpr size_t GZ_MAX_LINE = 4u << 20;
-    size_t gz_chunk_bytes = 0, gz_next = 0, gz_chain = 0, gz_lines = 0;
+    size_t gz_chunk_bytes = 0, gz_next = 0, gz_chain = 0, gz_lines = 0, gz_pending = 0;      // gz_pending: deferred blank lines (run_gz)
     uint64_t gz_pos = 0;
     bool gz_eos = false, gz_first_known = false, gz_verified = false, gz_text_ends_nl = false;
     uint8_t gz_first_byte = 0;

@@ -508,50 +508,64 @@ void FastqScanner::run_gz() {
             else
 #endif
                 list_newlines_generic(txt, 0, n, 0, nls);
-            // ---- chain B: line numbers and the unfinished line
+            // ---- chain B: line numbers, the unfinished line, and blank lines that may turn out to be the end of the stream
+            // Newlines at the end of a chunk beyond the one that ends its last line are blank lines; at the very end of the stream they
+            // are not records (the plain scanner cuts them off its mapping).  Whether they are the end only the chunks behind can
+            // tell, so they are DEFERRED: counted in gz_pending, neither numbered nor packed, and put back in front of the next chunk
+            // that brings anything but newlines (where they are what they are: malformed headers, empty sequence lines).
             std::vector<uint8_t> carry;
-            size_t n_txt = n;                          // the chunk's text without trailing blank lines at the very end of the stream
+            size_t n_txt = n, pend = 0;               // the chunk's text without its deferred newlines; blank lines put back in front of it
             bool final_open = false;                  // the stream ends with a line that has no newline
+            size_t n_complete = 0;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return stop || failed || gz_lines == k; });
                 if (stop || failed) return;
-                if (k == 0) { gz_first_byte = n ? txt[0] : 0; gz_first_known = true; }
-                carry = gz_carry;
+                if (k == 0) { gz_first_byte = n ? txt[0] : 0; gz_first_known = true; gz_text_ends_nl = true; }
+                size_t r = 0;
+                while (r < n && txt[n - 1 - r] == '\n') r++;
+                const size_t d = r == n ? (n ? r - (gz_text_ends_nl ? 0u : 1u) : 0u) : (r ? r - 1 : 0u);
+                n_txt = n - d;
+                for (size_t x = 0; x < d; x++) nls.pop_back();
                 blk.first_line = lines_so_far;
-                if (last) {
-                    // trailing blank lines at the very end are not records (as the plain scanner cuts them off its mapping)
-                    while (n_txt >= 1 && txt[n_txt - 1] == '\n' && (n_txt >= 2 ? txt[n_txt - 2] == '\n' : (carry.empty() && gz_text_ends_nl))) {
-                        n_txt--; nls.pop_back();
-                    }
+                if (n_txt) {
+                    carry = gz_carry;
+                    pend = gz_pending;
+                    gz_pending = d;
+                    n_complete = pend + nls.size();
+                    lines_so_far += n_complete;
+                    gz_text_ends_nl = txt[n_txt - 1] == '\n';
+                    if (nls.empty()) gz_carry.insert(gz_carry.end(), txt, txt + n_txt);
+                    else gz_carry.assign(txt + nls.back(), txt + n_txt);
+                    if (gz_carry.size() > GZ_MAX_LINE) throw Error("FASTQ line longer than " + std::to_string(GZ_MAX_LINE) + " bytes in " + path + " (--pack device reads lines of any length)");
+                } else {
+                    gz_pending += d;
+                    if (last) carry = gz_carry;        // (an unfinished last line is packed by the chunk that ends the stream, even an empty one)
                 }
-                lines_so_far += nls.size();
-                if (n_txt) gz_text_ends_nl = txt[n_txt - 1] == '\n';
-                if (nls.empty()) gz_carry.insert(gz_carry.end(), txt, txt + n_txt);
-                else gz_carry.assign(txt + nls.back(), txt + n_txt);
-                if (gz_carry.size() > GZ_MAX_LINE) throw Error("FASTQ line longer than " + std::to_string(GZ_MAX_LINE) + " bytes in " + path + " (--pack device reads lines of any length)");
                 if (last && !gz_carry.empty()) { final_open = true; lines_so_far++; }
                 gz_pieces[k] = std::move(pieces);
                 gz_lines = k + 1;
             }
             cv.notify_all();
-            // ---- pack: the text is (unfinished line in front) ++ (chunk); its lines that end inside the chunk
-            uint8_t *C = txt - carry.size();
-            if (carry.size() > ROOM) {                 // a very long line: a buffer of its own
+            // ---- pack: the text is (blank lines put back) ++ (unfinished line in front) ++ (chunk); its lines that end inside the chunk
+            const size_t front = pend + carry.size();
+            uint8_t *C = txt - front;
+            if (front > ROOM) {                        // a very long line (or very many blank lines): a buffer of its own
                 static thread_local std::vector<uint8_t> big;
-                big.resize(carry.size() + n_txt + 64);
-                memcpy(big.data() + carry.size(), txt, n_txt);
-                memset(big.data() + carry.size() + n_txt, 0, 64);
+                big.resize(front + n_txt + 64);
+                memcpy(big.data() + front, txt, n_txt);
+                memset(big.data() + front + n_txt, 0, 64);
                 C = big.data();
             }
-            if (!carry.empty()) memcpy(C, carry.data(), carry.size());
-            const size_t clen = carry.size() + n_txt;
+            if (pend) memset(C, '\n', pend);
+            if (!carry.empty()) memcpy(C + pend, carry.data(), carry.size());
+            const size_t clen = front + n_txt;
             if (clen) {
-                blk.starts.reserve(nls.size() + 1);
-                blk.starts.push_back(0);
-                for (uint32_t s : nls) if (s < n_txt) blk.starts.push_back((uint32_t)(carry.size() + s));
-                const size_t n_pack = nls.size() + (final_open ? 1 : 0);
-                extract(blk, C, 0, clen, n_pack, clen);
+                blk.starts.reserve(pend + nls.size() + 1);
+                for (size_t x = 0; x < pend; x++) blk.starts.push_back((uint32_t)x);
+                blk.starts.push_back((uint32_t)pend);
+                for (uint32_t s : nls) if (s < n_txt) blk.starts.push_back((uint32_t)(front + s));
+                extract(blk, C, 0, clen, n_complete + (final_open ? 1 : 0), clen);
             }
             {
                 std::lock_guard<std::mutex> lk(mu);

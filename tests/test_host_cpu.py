@@ -361,6 +361,20 @@ def test_scanner_packs_a_gzip_stream_like_its_text(tmp_path):
         for threads, block in ((2, 1 << 22), (4, 1 << 16), (3, 5000)):
             got, lines = hostlib.scan_records(str(tmp_path / name), 20, False, 30, True, threads=threads, block_bytes=block, cap=len(seqs) + 16)
             assert lines == 4 * len(seqs) and np.array_equal(got, want), (name, threads, block)
+    # blank lines at the end that sit in members (chunks) of their own, behind a CRLF text and behind an LF text: not records; the same
+    # blank lines with a record behind them: a malformed header
+    from sgcount_amd.bgzf import member, EOF_MARKER
+    for eol in (b"\n", b"\r\n"):
+        body = fastq(eol)
+        want_e = _pack_host(seqs, 20, False, 30, True)
+        (tmp_path / "tail.gz").write_bytes(bgzf_bytes(body, 20000, eof_marker=False) + member(b"\n") + member(b"\n\n") + EOF_MARKER)
+        for threads, block in ((3, 512), (2, 1 << 22)):
+            got, lines = hostlib.scan_records(str(tmp_path / "tail.gz"), 20, False, 30, True, threads=threads, block_bytes=block, cap=len(seqs) + 16)
+            assert lines == 4 * len(seqs) and np.array_equal(got, want_e), (eol, threads, block)
+        (tmp_path / "mid.gz").write_bytes(bgzf_bytes(body, 20000, eof_marker=False) + member(b"\n") + member(b"\n") + bgzf_bytes(b"@x" + eol + b"ACGT" + eol + b"+" + eol + b"IIII" + eol, 20000))
+        with pytest.raises(hostlib.HostError) as e:
+            hostlib.scan_records(str(tmp_path / "mid.gz"), 20, False, 30, True, threads=3, block_bytes=512, cap=len(seqs) + 16)
+        assert e.value.code == 101 and "line %d " % (4 * len(seqs) + 1) in str(e.value)
     blob = bytearray(bgzf_bytes(text, 30000)); blob[len(blob) // 2] ^= 0x10
     (tmp_path / "bbad.gz").write_bytes(bytes(blob))
     with pytest.raises(hostlib.HostError):
