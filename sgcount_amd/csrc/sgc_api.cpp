@@ -1325,7 +1325,7 @@ int sgc_sample_push_reads(sgc_sample *s, const uint8_t *seqs, const uint64_t *of
 
 int sgc_sample_push_windows(sgc_sample *s, const uint8_t *pieces, const uint64_t *offsets, uint64_t n, int where, uint32_t window_offset) {
     if (!s) return fail(SGC_E_ARG, "sgc_sample_push_windows: NULL argument");
-    if (window_offset > 1 || window_offset > s->offset) return fail(SGC_E_ARG, "sgc_sample_push_windows: window_offset is 1, or 0 for a sample with offset 0");
+    if (window_offset != (s->offset >= 1 ? 1u : 0u)) return fail(SGC_E_ARG, "sgc_sample_push_windows: window_offset is 1, or 0 for a sample with offset 0");
     // (every launch below takes the offset by value: the sample's own is back before anything else can look at it)
     const auto keep = s->offset;
     s->offset = window_offset;
