@@ -29,7 +29,10 @@ def main():
     cli = hostlib.cli_path()
     d = tempfile.mkdtemp()
     t0, n_cases = time.time(), 0
+    last_note = time.time()
     while time.time() - t0 < seconds:
+        if time.time() - last_note > 60:
+            print("... %d cases so far" % n_cases, flush=True); last_note = time.time()
         L, o, guides, reads = F.case(rng)
         reads = [r for r in reads if b"\n" not in r]
         if not reads or max(len(r) for r in reads) < L:       # count.rs:98-100 refuses a sample whose first read is shorter than the guides

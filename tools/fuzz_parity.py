@@ -61,7 +61,10 @@ def main():
     rng = random.Random(seed)
     S._ffi.load()
     t0, n_cases, n_checks = time.time(), 0, 0
+    last_note = time.time()
     while time.time() - t0 < seconds:
+        if time.time() - last_note > 60:
+            print("... %d cases so far" % n_cases, flush=True); last_note = time.time()
         L, o, guides, reads = case(rng)
         reverse = rng.random() < 0.4
         if reverse:
