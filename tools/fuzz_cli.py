@@ -18,6 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 import fuzz_parity as F                      # noqa: E402
 from test_cli_gpu import oracle_table         # noqa: E402
+import _oracle as O                          # noqa: E402
 from sgcount_amd import hostlib               # noqa: E402
 from sgcount_amd.bgzf import bgzf_bytes       # noqa: E402
 
@@ -66,7 +67,16 @@ def main():
         lib_text = b"".join(b">g%d\n%s\n" % (i, g) for i, g in enumerate(guides))
         lp = os.path.join(d, "lib.fa")
         open(lp, "wb").write(lib_text)
-        args = [cli, "-l", lp, "-i", path, "-a", str(o), "-q"]
+        oracle_text = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)) for i, r in enumerate(reads))
+        use = (reverse, o)
+        auto = rng.random() < 0.25 and not reverse
+        if auto:
+            # no -a: the entropy offsetter picks the offset (src/offsetter.rs); the oracle's choice is the expectation
+            try:
+                use = O.entropy_offset(lib_text, oracle_text)
+            except O.OracleError:
+                auto = False
+        args = [cli, "-l", lp, "-i", path] + ([] if auto else ["-a", str(o), "-q"])
         if exact: args.append("-x")
         if not recursion: args.append("-p")
         if reverse: args.append("-r")
@@ -76,15 +86,16 @@ def main():
         p = subprocess.run(args, capture_output=True, timeout=300)
         # the oracle reads what the reference would: CRLF lines end with '\r' for fxread too?  It strips them (as the scanner does), so
         # the oracle gets the reads themselves
-        want = oracle_table(lib_text, [b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)) for i, r in enumerate(reads))], ["s"], [(reverse, o)], exact, recursion)
-        if p.returncode != 0 or p.stdout.decode() != want:
+        want = oracle_table(lib_text, [oracle_text], ["s"], [use], exact, recursion)
+        said = "Calculated Offsets: [%s(%d)]" % ("Reverse" if use[0] else "Forward", use[1])
+        if p.returncode != 0 or p.stdout.decode() != want or (auto and said not in p.stderr.decode()):
             keep = os.path.join(ROOT, "gpurun_out", "fuzz_cli_fail")
             os.makedirs(keep, exist_ok=True)
             open(os.path.join(keep, os.path.basename(path)), "wb").write(blob)
             open(os.path.join(keep, "lib.fa"), "wb").write(lib_text)
             open(os.path.join(keep, "want.tsv"), "w").write(want)
             open(os.path.join(keep, "got.tsv"), "wb").write(p.stdout)
-            print("MISMATCH seed %d case %d: rc %d kind %s eol %r args %s\nstderr: %s" % (seed, n_cases, p.returncode, kind, eol, " ".join(args[1:]), p.stderr.decode()[-600:]))
+            print("MISMATCH seed %d case %d: rc %d kind %s eol %r auto %s expected offset %s args %s\nstderr: %s" % (seed, n_cases, p.returncode, kind, eol, auto, use, " ".join(args[1:]), p.stderr.decode()[-900:]))
             sys.exit(1)
         n_cases += 1
     print("cli fuzz ok: seed %d, %d cases in %.0f s" % (seed, n_cases, time.time() - t0))
