@@ -100,6 +100,24 @@ def main():
                         print("  guide", i, guides[i], "got", a, "want", b)
                 if only < 0:
                     sys.exit(1)
+        # ... and as FASTQ text cut at random line ends (any phase of the four-line cycle), every part pushed on its own
+        cuts = rng.randrange(0, 12)
+        where = rng.choice([0, 1])
+        announce = rng.random() < 0.7
+        if run and reads and len(reads) <= 5000:
+            import torch
+            from test_ingest_gpu import _count_parts, _cut_at_lines
+            text = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, r, b"I" * len(r)) for i, r in enumerate(reads))
+            parts = _cut_at_lines(text, random.Random(n_cases), cuts) or [text]
+            dl = lib.device(not exact, 0, opts)
+            ffi = S._ffi
+            got = _count_parts(torch, S, dl, parts, reverse, o, recursion, ffi.MEM_DEVICE if where else ffi.MEM_HOST, announce=announce)
+            n_checks += 1
+            if got != (want, tot, mat):
+                print("MISMATCH (fastq parts) seed %d case %d: L %d o %d reverse %s exact %s recursion %s opts %s parts %d where %d announce %s" % (
+                    seed, n_cases, L, o, reverse, exact, recursion, opts, len(parts), where, announce))
+                if only < 0:
+                    sys.exit(1)
         n_cases += 1
         if only >= 0 and n_cases > only:
             break
