@@ -42,7 +42,13 @@ def _deps(so):
 
 
 TARGETS[CHECK_SO] = TARGETS[SO]
-EXTRA_FLAGS = {CHECK_SO: ["-DSGC_CHECK=1"]}
+# experiment builds (tools/tune.py --lib ablate|stamps), never built by build(): timing-only ablation branches / phase stamps compiled in
+ABLATE_SO = os.path.join(PKG, "libsgcount_hip_ablate.so")
+STAMPS_SO = os.path.join(PKG, "libsgcount_hip_stamps.so")
+EXPERIMENT_SOS = {"ablate": ABLATE_SO, "stamps": STAMPS_SO}
+TARGETS[ABLATE_SO] = TARGETS[SO]
+TARGETS[STAMPS_SO] = TARGETS[SO]
+EXTRA_FLAGS = {CHECK_SO: ["-DSGC_CHECK=1"], ABLATE_SO: ["-DSGC_ABLATE=1"], STAMPS_SO: ["-DSGC_STAMPS=1"]}
 
 
 def needs_build(so=SO):
@@ -53,12 +59,36 @@ def needs_build(so=SO):
 
 
 def build_one(so, force=False, verbose=False):
+    """One object per source, compiled side by side (the kernels of one file take most of a minute), then linked.  The objects are
+    kept under build/<library name>/ and reused while the source, every header and the flags are unchanged."""
     if not force and not needs_build(so):
         return so
-    srcs, _ = TARGETS[so]
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-result", "-Wno-unused-value"] + EXTRA_FLAGS.get(so, []) + os.environ.get("SGC_HIPCC_FLAGS", "").split() + \
-          ["-o", so] + [os.path.join(CSRC, f) for f in srcs]      # SGC_HIPCC_FLAGS: e.g. -DSGC_STAMPS=1 (tools/evidence.sh)
+    from concurrent.futures import ThreadPoolExecutor
+    srcs, hdrs = TARGETS[so]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-Wno-unused-value"] + \
+            EXTRA_FLAGS.get(so, []) + os.environ.get("SGC_HIPCC_FLAGS", "").split()      # SGC_HIPCC_FLAGS: e.g. -DSGC_STAMPS=1
+    odir = os.path.join(PKG, "build", os.path.basename(so))
+    os.makedirs(odir, exist_ok=True)
+    stamp = os.path.join(odir, "flags.txt")
+    same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in hdrs if os.path.exists(os.path.join(CSRC, h)))
+    hdr_t = max(hdr_t, os.path.getmtime(os.path.abspath(__file__)))
+
+    def one(f):
+        src, obj = os.path.join(CSRC, f), os.path.join(odir, f.replace(os.sep, "_") + ".o")
+        if not force and same_flags and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
+            return obj
+        cmd = [_hipcc()] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(one, srcs))
+    with open(stamp, "w") as fh:
+        fh.write(" ".join(flags))
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
@@ -96,7 +126,8 @@ def build_host(force=False, verbose=False):
 
 def build(force=False, verbose=False):
     for so in TARGETS:
-        build_one(so, force, verbose)
+        if so not in EXPERIMENT_SOS.values():
+            build_one(so, force, verbose)
     build_host(force, verbose)
     return SO
 

@@ -2,8 +2,10 @@
 // flow (src/main.rs:142-203).  `sgcount-hip -l library.fa -i a.fq.gz b.fq.gz [-a 30] [-x] [-p] [-r] [-g g2s.txt] ...`
 #include <cstdio>
 #include <cstdlib>
+#include <cctype>
 #include <cstring>
 #include <fstream>
+#include <stdexcept>
 
 #include "sgh.hpp"
 
@@ -46,64 +48,160 @@ static const char *USAGE =
 
 static bool file_exists(const std::string &p) { std::ifstream f(p); return f.good(); }
 
+// The argument forms clap 4 accepts for the reference's `Args` (src/main.rs:54-108, clap 4.5 derive): `--long value`, `--long=value`,
+// `-s value`, `-svalue`, `-s=value`, bundled shorts (`-xzq`, `-xa 5`, `-xa5`), `--` (no positionals exist: whatever follows is an
+// unexpected argument), options with num_args = 1.. (`-i a b -i c`), and clap's errors (exit code 2): a single-valued option or a
+// flag given twice, a value attached to a flag, a missing value, an unknown argument.
+namespace {
+enum Kind { FLAG, ONE, MANY };
+struct Spec { char s; const char *l; Kind kind; const char *shown; };      // shown: how clap names the argument in its messages
+const Spec SPECS[] = {
+    {'l', "library-path", ONE, "--library-path <LIBRARY_PATH>"}, {'i', "input-paths", MANY, "--input-paths <INPUT_PATHS>..."},
+    {'n', "sample-names", MANY, "--sample-names <SAMPLE_NAMES>..."}, {'o', "output-path", ONE, "--output-path <OUTPUT_PATH>"},
+    {'g', "genemap", ONE, "--genemap <GENEMAP>"}, {'a', "offset", ONE, "--offset <OFFSET>"},
+    {'p', "no-position-recursion", FLAG, "--no-position-recursion"}, {'r', "reverse", FLAG, "--reverse"}, {'x', "exact", FLAG, "--exact"},
+    {'s', "subsample", ONE, "--subsample <SUBSAMPLE>"}, {'t', "threads", ONE, "--threads <THREADS>"}, {'q', "quiet", FLAG, "--quiet"},
+    {'z', "include-zero", FLAG, "--include-zero"}, {'h', "help", FLAG, "--help"}, {'V', "version", FLAG, "--version"},
+    // not in the reference: BASELINE.json's name for its default, and the knobs of this implementation (long form only)
+    {0, "include-permutations", FLAG, "--include-permutations"}, {0, "pack", ONE, "--pack"}, {0, "scan-threads", ONE, "--scan-threads"},
+    {0, "scan-source", ONE, "--scan-source"}, {0, "scan-block-kb", ONE, "--scan-block-kb"}, {0, "io-threads", ONE, "--io-threads"},
+    {0, "chunk-mb", ONE, "--chunk-mb"}, {0, "devices", ONE, "--devices"}, {0, "stats-json", ONE, "--stats-json"}, {0, "exit", ONE, "--exit"},
+    {0, "dry-run-args", FLAG, "--dry-run-args"},
+};
+struct UsageError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct Occurrence { const Spec *spec; std::vector<std::string> values; };
+const Spec *find_long(const std::string &name) { for (const Spec &sp : SPECS) if (name == sp.l) return &sp; return nullptr; }
+const Spec *find_short(char c) { for (const Spec &sp : SPECS) if (sp.s && sp.s == c) return &sp; return nullptr; }
+
+// argv -> the occurrences of the arguments, in order (one per appearance; a MANY occurrence holds the values that followed it)
+std::vector<Occurrence> tokenize(int argc, char **argv) {
+    std::vector<Occurrence> occ;
+    const Spec *pending = nullptr;          // an option still taking values: ONE with none yet, or MANY
+    auto close_pending = [&]() {
+        if (pending && occ.back().values.empty()) throw UsageError(std::string("a value is required for '") + pending->shown + "' but none was supplied");
+        pending = nullptr;
+    };
+    auto open = [&](const Spec *sp, bool has_attached, const std::string &attached) {
+        close_pending();
+        occ.push_back({sp, {}});
+        if (sp->kind == FLAG) {
+            if (has_attached) throw UsageError("unexpected value '" + attached + "' for '" + sp->shown + "' found; no more were expected");
+            return;
+        }
+        if (has_attached) { occ.back().values.push_back(attached); if (sp->kind == MANY) pending = sp; }
+        else pending = sp;
+    };
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        if (a == "--") {                    // ends the values of a pending option; there are no positionals to take what follows
+            close_pending();
+            if (i + 1 < argc) throw UsageError(std::string("unexpected argument '") + argv[i + 1] + "' found");
+            break;
+        }
+        if (a.size() > 2 && a[0] == '-' && a[1] == '-') {
+            const size_t eq = a.find('=');
+            const std::string name = a.substr(2, eq == std::string::npos ? std::string::npos : eq - 2);
+            const Spec *sp = find_long(name);
+            if (!sp) throw UsageError("unexpected argument '--" + name + "' found");
+            open(sp, eq != std::string::npos, eq == std::string::npos ? "" : a.substr(eq + 1));
+            continue;
+        }
+        if (a.size() > 1 && a[0] == '-') {  // a bundle of shorts; the first one that takes a value takes the rest of the bundle
+            for (size_t k = 1; k < a.size(); k++) {
+                const Spec *sp = find_short(a[k]);
+                if (!sp) throw UsageError(k == 1 ? "unexpected argument '" + a + "' found" : std::string("unexpected argument '-") + a[k] + "' found");
+                if (sp->kind == FLAG) {
+                    if (k + 1 < a.size() && a[k + 1] == '=') throw UsageError("unexpected value '" + a.substr(k + 2) + "' for '" + sp->shown + "' found; no more were expected");
+                    open(sp, false, "");
+                    continue;
+                }
+                std::string rest = a.substr(k + 1);
+                if (!rest.empty() && rest[0] == '=') rest.erase(0, 1);
+                open(sp, k + 1 < a.size(), rest);
+                break;
+            }
+            continue;
+        }
+        if (!pending) throw UsageError("unexpected argument '" + a + "' found");
+        occ.back().values.push_back(a);
+        if (pending->kind == ONE) pending = nullptr;
+    }
+    close_pending();
+    // clap: only arguments that append (Vec) may appear more than once
+    for (size_t x = 0; x < occ.size(); x++)
+        for (size_t y = 0; y < x; y++)
+            if (occ[x].spec == occ[y].spec && occ[x].spec->kind != MANY)
+                throw UsageError(std::string("the argument '") + occ[x].spec->shown + "' cannot be used multiple times");
+    return occ;
+}
+std::string json_str(const std::string &v) {
+    std::string o = "\"";
+    for (char c : v) { if (c == '"' || c == '\\') o += '\\'; o += c; }
+    return o + "\"";
+}
+const char *USAGE_LINE = "Usage: sgcount-hip [OPTIONS] --library-path <LIBRARY_PATH> --input-paths <INPUT_PATHS>...\n\nFor more information, try '--help'.\n";
+}  // namespace
+
 int cli_main(int argc, char **argv) {
     try {
         CountOptions opt;
         std::string genemap_path;
-        bool have_offset = false, reverse = false, have_sub = false;
+        bool have_offset = false, reverse = false, have_sub = false, dry_run = false;
         size_t offset = 0, subsample = 5000;
         bool have_names = false;
-        auto need = [&](int &i, const char *flag) -> std::string {
-            if (i + 1 >= argc) throw Error(std::string("a value is required for '") + flag + "' but none was supplied");
-            return argv[++i];
-        };
-        auto multi = [&](int &i, std::vector<std::string> &dst) {
-            while (i + 1 < argc && !(argv[i + 1][0] == '-' && argv[i + 1][1] != '\0')) dst.push_back(argv[++i]);
-        };
         auto to_num = [&](const std::string &v, const char *flag) -> size_t {
             char *e = nullptr;
             const unsigned long long x = strtoull(v.c_str(), &e, 10);
-            if (v.empty() || *e || v[0] == '-') throw Error("invalid value '" + v + "' for '" + flag + "': invalid digit found in string");
+            if (v.empty() || *e || v[0] == '-' || v[0] == '+' || isspace((unsigned char)v[0]))
+                throw UsageError("invalid value '" + v + "' for '" + flag + "': " + (v.empty() ? "cannot parse integer from empty string" : "invalid digit found in string"));
             return (size_t)x;
         };
-        for (int i = 1; i < argc; i++) {
-            const std::string a = argv[i];
-            if (a == "-l" || a == "--library-path") opt.library_path = need(i, "--library-path <LIBRARY_PATH>");
-            else if (a == "-i" || a == "--input-paths") multi(i, opt.input_paths);
-            else if (a == "-n" || a == "--sample-names") { multi(i, opt.sample_names); have_names = true; }
-            else if (a == "-o" || a == "--output-path") opt.output_path = need(i, "--output-path <OUTPUT_PATH>");
-            else if (a == "-g" || a == "--genemap") genemap_path = need(i, "--genemap <GENEMAP>");
-            else if (a == "-a" || a == "--offset") { offset = to_num(need(i, "--offset <OFFSET>"), "--offset <OFFSET>"); have_offset = true; }
-            else if (a == "-p" || a == "--no-position-recursion") opt.position_recursion = false;
-            else if (a == "-r" || a == "--reverse") reverse = true;
-            else if (a == "-x" || a == "--exact") opt.exact = true;
-            else if (a == "-s" || a == "--subsample") { subsample = to_num(need(i, "--subsample <SUBSAMPLE>"), "--subsample <SUBSAMPLE>"); have_sub = true; }
-            else if (a == "-t" || a == "--threads") opt.threads = to_num(need(i, "--threads <THREADS>"), "--threads <THREADS>");
-            else if (a == "-q" || a == "--quiet") opt.quiet = true;
-            else if (a == "-z" || a == "--include-zero") opt.include_zero = true;
-            else if (a == "--include-permutations") { /* BASELINE.json's name for the reference default; no-op */ }
-            else if (a == "--pack") {
-                const std::string v = need(i, "--pack");
-                if (v != "host" && v != "device" && v != "fastq" && v != "scan") throw Error("invalid value '" + v + "' for '--pack'");
-                opt.device_pack = v != "host";
-                opt.device_parse = v == "fastq" || v == "scan";
-                opt.host_scan = v == "scan";
+        std::vector<Occurrence> occ;
+        try {
+            occ = tokenize(argc, argv);
+            // --help / --version win over everything else on the line, as in clap
+            for (const Occurrence &o : occ) {
+                if (!strcmp(o.spec->l, "help")) { fputs(USAGE, stdout); return 0; }
+                if (!strcmp(o.spec->l, "version")) { puts("sgcount-hip 0.1.0 (count path of sgcount 0.1.35)"); return 0; }
             }
-            else if (a == "--scan-threads") opt.scan_threads = to_num(need(i, "--scan-threads"), "--scan-threads");
-            else if (a == "--scan-source") {
-                const std::string v = need(i, "--scan-source");
-                if (v != "auto" && v != "mmap" && v != "read") throw Error("invalid value '" + v + "' for '--scan-source'");
-                opt.scan_source = v == "mmap" ? 1 : (v == "read" ? 2 : 0);
+            for (const Occurrence &o : occ) {
+                const std::string n = o.spec->l, v = o.values.empty() ? "" : o.values[0];
+                if (n == "library-path") opt.library_path = v;
+                else if (n == "input-paths") opt.input_paths.insert(opt.input_paths.end(), o.values.begin(), o.values.end());
+                else if (n == "sample-names") { opt.sample_names.insert(opt.sample_names.end(), o.values.begin(), o.values.end()); have_names = true; }
+                else if (n == "output-path") opt.output_path = v;
+                else if (n == "genemap") genemap_path = v;
+                else if (n == "offset") { offset = to_num(v, o.spec->shown); have_offset = true; }
+                else if (n == "no-position-recursion") opt.position_recursion = false;
+                else if (n == "reverse") reverse = true;
+                else if (n == "exact") opt.exact = true;
+                else if (n == "subsample") { subsample = to_num(v, o.spec->shown); have_sub = true; }
+                else if (n == "threads") opt.threads = to_num(v, o.spec->shown);
+                else if (n == "quiet") opt.quiet = true;
+                else if (n == "include-zero") opt.include_zero = true;
+                else if (n == "include-permutations") { /* BASELINE.json's name for the reference default; no-op */ }
+                else if (n == "pack") {
+                    if (v != "host" && v != "device" && v != "fastq" && v != "scan") throw UsageError("invalid value '" + v + "' for '--pack'");
+                    opt.device_pack = v != "host";
+                    opt.device_parse = v == "fastq" || v == "scan";
+                    opt.host_scan = v == "scan";
+                }
+                else if (n == "scan-threads") opt.scan_threads = to_num(v, "--scan-threads");
+                else if (n == "scan-source") {
+                    if (v != "auto" && v != "mmap" && v != "read") throw UsageError("invalid value '" + v + "' for '--scan-source'");
+                    opt.scan_source = v == "mmap" ? 1 : (v == "read" ? 2 : 0);
+                }
+                else if (n == "scan-block-kb") opt.scan_block_bytes = to_num(v, "--scan-block-kb") << 10;
+                else if (n == "io-threads") opt.io_threads = to_num(v, "--io-threads");
+                else if (n == "chunk-mb") opt.chunk_bytes = to_num(v, "--chunk-mb") << 20;
+                else if (n == "devices") opt.max_devices = to_num(v, "--devices");
+                else if (n == "stats-json") opt.stats_path = v;
+                else if (n == "exit") { if (v != "fast" && v != "clean") throw UsageError("invalid value '" + v + "' for '--exit'"); }
+                else if (n == "dry-run-args") dry_run = true;
             }
-            else if (a == "--scan-block-kb") opt.scan_block_bytes = to_num(need(i, "--scan-block-kb"), "--scan-block-kb") << 10;
-            else if (a == "--io-threads") opt.io_threads = to_num(need(i, "--io-threads"), "--io-threads");
-            else if (a == "--chunk-mb") opt.chunk_bytes = to_num(need(i, "--chunk-mb"), "--chunk-mb") << 20;
-            else if (a == "--devices") opt.max_devices = to_num(need(i, "--devices"), "--devices");
-            else if (a == "--stats-json") opt.stats_path = need(i, "--stats-json");
-            else if (a == "--exit") { const std::string v = need(i, "--exit"); if (v != "fast" && v != "clean") throw Error("invalid value '" + v + "' for '--exit'"); }
-            else if (a == "-h" || a == "--help") { fputs(USAGE, stdout); return 0; }
-            else if (a == "-V" || a == "--version") { puts("sgcount-hip 0.1.0 (count path of sgcount 0.1.35)"); return 0; }
-            else { fprintf(stderr, "error: unexpected argument '%s' found\n\n%s", a.c_str(), USAGE); return 2; }
+        } catch (const UsageError &e) {
+            fprintf(stderr, "error: %s\n\n%s", e.what(), USAGE_LINE);
+            return 2;
         }
         (void)have_sub;
         if (opt.library_path.empty() || opt.input_paths.empty()) {
@@ -111,6 +209,21 @@ int cli_main(int argc, char **argv) {
                     opt.library_path.empty() ? "  --library-path <LIBRARY_PATH>\n" : "",
                     opt.input_paths.empty() ? "  --input-paths <INPUT_PATHS>..." : "", USAGE);
             return 2;
+        }
+        if (dry_run) {
+            // what the line parsed to, and nothing else (no file is opened, no device): tests/test_host_cpu.py's table of argument forms
+            std::string j = "{\"library_path\": " + json_str(opt.library_path) + ", \"input_paths\": [";
+            for (size_t i = 0; i < opt.input_paths.size(); i++) j += (i ? ", " : "") + json_str(opt.input_paths[i]);
+            j += "], \"sample_names\": ";
+            if (have_names) { j += "["; for (size_t i = 0; i < opt.sample_names.size(); i++) j += (i ? ", " : "") + json_str(opt.sample_names[i]); j += "]"; }
+            else j += "null";
+            j += ", \"output_path\": " + json_str(opt.output_path) + ", \"genemap\": " + json_str(genemap_path) +
+                 ", \"offset\": " + (have_offset ? std::to_string(offset) : "null") + ", \"subsample\": " + (have_sub ? std::to_string(subsample) : "null") +
+                 ", \"threads\": " + std::to_string(opt.threads) + ", \"no_position_recursion\": " + (opt.position_recursion ? "false" : "true") +
+                 ", \"reverse\": " + (reverse ? "true" : "false") + ", \"exact\": " + (opt.exact ? "true" : "false") +
+                 ", \"quiet\": " + (opt.quiet ? "true" : "false") + ", \"include_zero\": " + (opt.include_zero ? "true" : "false") + "}";
+            puts(j.c_str());
+            return 0;
         }
         for (const auto &p : opt.input_paths)                                          // main.rs:130-140 validate_paths
             if (!file_exists(p)) throw Panic("Provided filepath does not exist: " + p);
@@ -163,8 +276,8 @@ int main(int argc, char **argv) {
     // Everything observable is written and closed by now, the contexts are freed: end the process without the user-space
     // teardown of the HIP runtime (static destructors, atexit handlers: 20-100 ms) — the kernel releases the device either
     // way.  `--exit clean` returns through exit() instead (sanitizers, leak checkers).
-    for (int i = 1; i + 1 < argc; i++)
-        if (!strcmp(argv[i], "--exit") && !strcmp(argv[i + 1], "clean")) return rc;
+    for (int i = 1; i < argc; i++)
+        if (!strcmp(argv[i], "--exit=clean") || (i + 1 < argc && !strcmp(argv[i], "--exit") && !strcmp(argv[i + 1], "clean"))) return rc;
     fflush(stdout); fflush(stderr);
     _exit(rc);
 }

@@ -75,6 +75,7 @@ struct sgc_ctx {
     uint64_t place_info[4] = {0, 0, 0, 0};   // last search: candidates tried, peak transient bytes, duration in us, index of the one kept
     void *placed_pool = nullptr;       // the pool the trials chose (they run again if it was re-allocated since)
     bool six_byte = true;              // ... and the slice blocks hold six-byte records (needs direct, L <= 21)
+    bool wide = true;                  // k_count_slices reads its five-byte blocks 256 consecutive records per wave (16-byte loads)
     bool five_byte = true;             // ... or five-byte records (needs direct and enough slices: 2 (L + 2) - slice bits <= 40)
     bool tag_sub = true;               // K1 tags the pass-A partition inside the slice, K2 counts misses by it (no histogram sweep)
     bool use_cuckoo = true;            // k_count_slices probes the two-choice image of the slices (no chain loop)
@@ -435,7 +436,7 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n, bool
                 if (tag_sub) ra.sub_bits = (uint32_t)sub;
                 uint32_t *mcur = (uint32_t *)zeroed + 2 * RUN_MAXP + 2;        // behind totals A | totals B | region cursors (zeroed by K1)
                 { timed t(c, T_LOOKUP, true); sgc_launch_part_k2(c->stream, c->L, c->v_lib, g, pool, desc, c32, s->d_matched, c->dbg, &ra,
-                                                                 c->use_cuckoo ? c->d_lib_cuckoo : nullptr, mrun, mcur, direct, six, tot, tot_next); }
+                                                                 c->use_cuckoo ? c->d_lib_cuckoo : nullptr, mrun, mcur, direct, six, tot, tot_next, c->wide); }
                 if (bal) c->tot_parity ^= 1;
                 // timing: miss_ms = core pass A (+ its epilogue), hist_ms = core pass B
                 if (!c->one_mm) {
@@ -670,7 +671,7 @@ int sgc_ctx_clone(sgc_ctx *src, sgc_ctx **out) {
     // and the options that shape the passes
     c->variant = src->variant; c->per_lane = src->per_lane; c->k1_wgs = src->k1_wgs; c->max_chunk = src->max_chunk;
     c->batch_records = src->batch_records; c->dense = src->dense; c->direct = src->direct; c->six_byte = src->six_byte;
-    c->five_byte = src->five_byte; c->balanced = src->balanced; c->tag_sub = src->tag_sub; c->use_cuckoo = src->use_cuckoo; c->place_trials = src->place_trials;
+    c->five_byte = src->five_byte; c->wide = src->wide; c->balanced = src->balanced; c->tag_sub = src->tag_sub; c->use_cuckoo = src->use_cuckoo; c->place_trials = src->place_trials;
     c->verbose = src->verbose; c->host_routes = src->host_routes;
     *out = c;
     return SGC_OK;
@@ -727,6 +728,7 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
     if (!strcmp(key, "direct")) { c->direct = value != 0; return SGC_OK; }
     if (!strcmp(key, "six_byte")) { c->six_byte = value != 0; return SGC_OK; }
     if (!strcmp(key, "five_byte")) { c->five_byte = value != 0; return SGC_OK; }
+    if (!strcmp(key, "wide")) { c->wide = value != 0; return SGC_OK; }
     if (!strcmp(key, "tag_sub")) { c->tag_sub = value != 0; return SGC_OK; }
     if (!strcmp(key, "cuckoo")) { c->use_cuckoo = value != 0; return SGC_OK; }
     if (!strcmp(key, "rest_filter")) { c->rest_filter = value != 0; return SGC_OK; }         // takes effect at the next sgc_set_library

@@ -85,7 +85,8 @@ void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, c
                         int slice_rec /* as given to sgc_launch_part_k1 */,
                         const uint32_t *slice_tot /* what k_partition added up (direct runs only), or NULL = static shares: the same
                                                      number of workgroups for every slice */,
-                        uint32_t *slice_tot_next /* with slice_tot: SGC_SLICE_TOT words the kernel zeroes for the next pass */);
+                        uint32_t *slice_tot_next /* with slice_tot: SGC_SLICE_TOT words the kernel zeroes for the next pass */,
+                        bool wide = true /* five-byte blocks of a 20-base library: 256 consecutive records per wave, 16-byte loads */);
 void sgc_launch_part_k3(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm,
                         const sgc_bloom_view &bloom_lib, const sgc_bloom_view &bloom_perm, const sgc_part_geometry &g,
                         const uint64_t *pool, const uint32_t *desc, uint32_t *seg_cnt, uint32_t *gids, uint32_t dbg);

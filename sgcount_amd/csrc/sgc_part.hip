@@ -298,6 +298,9 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
 #define K2_U 8u 
 #endif
 //                 // blocks per group: one group is processed while the next is in flight
+#ifndef K2_WU
+#define K2_WU 2u                 // WIDE: steps (four records per lane each) per group
+#endif
 #define K2_SCAN 16u              // descriptors examined per lane per scan chunk
 #define K2_GLIST 64u             // generic blocks listed per epilogue window
 // record j of slice block b
@@ -349,7 +352,12 @@ __device__ __forceinline__ uint32_t k2_slice_wgs(const uint32_t *spre, uint32_t 
 // LT: 20 = the geometry of a 20-base library with 64 full slices as compile-time constants (guide length, core length 9, six slice
 // bits, two sub-partition bits): the record decode and the probe become shifts and masks by immediates instead of 64-bit shifts
 // by scalars — the loop of this kernel is as much vector issue as it is memory; 0 = everything from the arguments.
-template <int LOG2_SLICE, bool CUCKOO, bool DENSE, bool DIRECT, int REC, int LT = 0>
+// WIDE (five-byte blocks, direct runs, two-choice image): a wave takes 256 CONSECUTIVE records of a block — lane l the four
+// records 4 l .. 4 l + 3, one 16-byte load (their low words) and one 4-byte load (their high bytes) per lane — instead of one
+// record per lane from eight different blocks (a 4-byte and a 1-byte load per record).  The same bytes in a quarter of the
+// vector-memory instructions: what bounded the narrow loop was the number of memory instructions a CU keeps in flight, not the
+// bytes (DESIGN.md §6 "What bounds k_count_slices", round 4).
+template <int LOG2_SLICE, bool CUCKOO, bool DENSE, bool DIRECT, int REC, int LT = 0, bool WIDE = false>
 __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(80))) k_count_slices(uint64_t *__restrict__ pool, uint32_t *__restrict__ desc,
                                                              const uint32_t *__restrict__ wcnt, const uint32_t *__restrict__ wlist,
                                                              uint32_t k1_wgs, uint32_t blocks_per_wg, uint32_t G, uint32_t L_arg,
@@ -493,6 +501,71 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
         }
         __syncthreads();
         if (SGC_STAMPS && (dbg & (512u | 1048576u))) { ts_scan += __builtin_amdgcn_s_memtime() - ts0; ts0 = __builtin_amdgcn_s_memtime(); n_groups_dbg += (nl + K2_U * (K2_THREADS / PART_BLOCK) - 1) / (K2_U * (K2_THREADS / PART_BLOCK)); }
+        if constexpr (WIDE) {
+            static_assert(!WIDE || (REC == 2 && DIRECT && CUCKOO && PART_ROT == 0 && PART_BLOCK % 256u == 0), "wide loads: five-byte blocks, direct runs, two-choice image");
+            constexpr uint32_t QPB = PART_BLOCK / 256u;                 // 256-record pieces per block
+            constexpr uint32_t BPW = (K2_THREADS / 64u) / QPB;          // blocks per step of the workgroup
+            constexpr uint32_t WU = K2_WU;                              // steps per group: one group is processed while the next is in flight
+            const uint32_t wvi = __builtin_amdgcn_readfirstlane(t >> 6);
+            const uint32_t hb = wvi / QPB, j0 = (wvi % QPB) * 256u + 4u * (t & 63u);
+            const uint32_t nsteps = (nl + BPW - 1u) / BPW;
+            const char *const pb = reinterpret_cast<const char *>(pool);
+            // timing-only ablations (-DSGC_ABLATE=1): dbg 1 no pool loads, 2 no table reads, 4 no miss stores, 8 no LDS atomics, 32 the blocks
+            // of a share read from consecutive pool addresses instead of where they are
+#define K2W_ENTRY(s) __builtin_amdgcn_readfirstlane((s) * BPW + hb < nl ? (SGC_DBG(dbg, 32u) ? ((((blockIdx.x * (s_hi - s_lo) + (win - s_lo) + (s) * BPW + hb) % (k1_wgs * blocks_per_wg)) << 11) | (list[(s) * BPW + hb] & 2047u)) : list[(s) * BPW + hb]) : 0xFFFFFFFFu)
+            // (unconditional loads: a lane past the block's fill reads the block's first 16 bytes again — a line that is on its way
+            // anyway — and a wave without a block the pool's; loads inside branches make the compiler wait for every load in flight)
+#define K2W_LOAD(e, lo, hi)                                                                                          \
+            {                                                                                                        \
+                const uint32_t e_ = (e);                                                                             \
+                const char *bb_ = pb + (e_ != 0xFFFFFFFFu ? (uint64_t)(e_ >> 11) * (PART_STRIDE * 8u) : 0ull);       \
+                const uint32_t jj_ = (e_ != 0xFFFFFFFFu && j0 <= (e_ & 2047u)) ? j0 : 0u;                            \
+                if (SGC_DBG(dbg, 1u)) { lo = make_uint4(e_ * 2654435761u + t, e_ * 40503u + t * 77u, e_ + 3u * t, e_ ^ (t << 7)); hi = e_ + t; } else { \
+                lo = *reinterpret_cast<const uint4 *>(bb_ + 4u * jj_);                                               \
+                hi = *reinterpret_cast<const uint32_t *>(bb_ + P6_HI_OFF + jj_); }                                   \
+            }
+            uint4 clo[WU], nlo[WU];
+            uint32_t chi[WU], nhi[WU], ce[WU];
+#pragma unroll
+            for (uint32_t u = 0; u < WU; u++) { ce[u] = K2W_ENTRY(u); K2W_LOAD(ce[u], clo[u], chi[u]) }
+            for (uint32_t li = 0; li < nsteps; li += WU) {
+#pragma unroll
+                for (uint32_t u = 0; u < WU; u++) K2W_LOAD(K2W_ENTRY(li + WU + u), nlo[u], nhi[u])
+#pragma unroll
+                for (uint32_t u = 0; u < WU; u++) {
+                    const uint32_t lw[4] = {clo[u].x, clo[u].y, clo[u].z, clo[u].w};
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) {
+                        const bool valid = ce[u] != 0xFFFFFFFFu && j0 + k <= (ce[u] & 2047u);
+                        // five-byte record -> span (as in the narrow loop below)
+                        const uint32_t cb = 2u * core_cl, kb = cb - slice_bits;
+                        const uint32_t raw_lo = lw[k];
+                        const uint64_t raw = (uint64_t)raw_lo | ((uint64_t)((chi[u] >> (8u * k)) & 0xFFu) << 32);
+                        const uint32_t hmix = (p << kb) | ((raw_lo >> 4) & ((1u << kb) - 1u));
+                        const uint32_t corev = sgc_core_unmix(hmix, core_cl);
+                        const uint64_t span = (uint64_t)(raw_lo & 0xFu) | ((uint64_t)corev << 4) | ((raw >> (4u + kb)) << (4u + cb));
+                        const uint32_t sub = (hmix >> (kb - sub_bits)) & ((1u << sub_bits) - 1u);
+                        const uint64_t key = (span >> 2) & kmask;
+                        const uint32_t h32 = sgc_hash32(key);
+                        const uint32_t s1 = h32 >> (32u - ls), s2 = sgc_cuckoo_alt_h(h32, s1, ls);
+                        const uint64_t e1 = SGC_DBG(dbg, 2u) ? (uint64_t)(s1 & 7u ? key : 0ull) : tab1[s1], e2 = SGC_DBG(dbg, 2u) ? 0ull : tab1[s2];
+                        const bool h2 = e2 == key, hit = e1 == key || h2;
+                        const uint32_t slot = h2 ? s2 : s1;
+                        const bool hv = valid && hit, mv = valid && !hit;
+                        if (!SGC_DBG(dbg, 8u)) atomicAdd(hv ? &cnt[slot] : &scratch[t & 63u], 1u);
+                        const uint32_t pos = SGC_DBG(dbg, 8u) ? (slot * 7u) % (stretch ? stretch : 1u) : atomicAdd(mv ? &wmiss4[sub] : &scratch[64u + (t & 63u)], 1u);
+                        if (mv && !SGC_DBG(dbg, 4u) && SGC_BOUND(pos < stretch, reinterpret_cast<unsigned long long *>(matched) + 3, 11)) mrun[(uint64_t)run0 + sgc_mul24(sub, stretch) + pos] = span;
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < WU; u++) { clo[u] = nlo[u]; chi[u] = nhi[u]; ce[u] = K2W_ENTRY(li + WU + u); }
+            }
+#undef K2W_LOAD
+#undef K2W_ENTRY
+            __syncthreads();
+            if (SGC_STAMPS && (dbg & (512u | 1048576u))) { ts_loop += __builtin_amdgcn_s_memtime() - ts0; ts0 = __builtin_amdgcn_s_memtime(); }
+            continue;
+        }
         // software pipeline over groups of K2_U blocks: `cur` is processed while `nxt` is in flight.  Block ids and
         // fills are wave-uniform (scalar registers).
         uint64_t cur[Q], nxt[Q];
@@ -1019,7 +1092,7 @@ uint32_t sgc_part_k2_direct_cols(const sgc_part_geometry &g, bool balanced) {
 void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, const sgc_part_geometry &g,
                         uint64_t *pool, uint32_t *desc, uint32_t *counts, unsigned long long *matched, uint32_t dbg,
                         const sgc_runs *runs, const uint64_t *cuckoo, uint64_t *mrun, uint32_t *mcur, bool direct_runs, int slice_rec,
-                        const uint32_t *slice_tot, uint32_t *slice_tot_next) {
+                        const uint32_t *slice_tot, uint32_t *slice_tot_next, bool wide) {
     const uint32_t grid = g.partitions * k2_shares(g);
     // balanced shares (slice_tot: k_partition's blocks per slice; direct runs only): any workgroup may work on any slice, so the run
     // matrices keep `grid` columns for the direct runs; static shares: the k2_shares(g) workgroups of a slice
@@ -1035,7 +1108,10 @@ void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, c
     const int rec = direct ? slice_rec : 0;          // 0 = 8-byte, 1 = six-byte, 2 = five-byte slice blocks
     const bool l20 = L == 20 && rec == 2 && cuckoo && lib.core_cl == 9 && lib.log2_slice == SGC_LDS_LOG2_SLICE &&
                      lib.log2_slots == SGC_LDS_LOG2_SLICE + 6u && runs->sub_bits == 2;
-    if (l20)
+    if (l20 && wide)
+        hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE, true, true, true, 2, 20, true>), dim3(grid), dim3(K2_THREADS), sgc_extra_lds("K2"), st, pool, desc, wcnt, wlist,
+                           g.k1_wgs, g.blocks_per_wg, G, L, lib, counts, matched, dbg, *runs, cuckoo, mrun, mcur, slice_tot, slice_tot_next);
+    else if (l20)
         hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE, true, true, true, 2, 20>), dim3(grid), dim3(K2_THREADS), sgc_extra_lds("K2"), st, pool, desc, wcnt, wlist,
                            g.k1_wgs, g.blocks_per_wg, G, L, lib, counts, matched, dbg, *runs, cuckoo, mrun, mcur, slice_tot, slice_tot_next);
     else if (cuckoo) { if (rec == 2) K2_LAUNCH(true, true, true, 2); else if (rec == 1) K2_LAUNCH(true, true, true, 1); else if (direct) K2_LAUNCH(true, true, true, 0); else if (dense) K2_LAUNCH(true, true, false, 0); else K2_LAUNCH(true, false, false, 0); }

@@ -502,3 +502,77 @@ def test_folded_crc32_equals_zlib():
         b = b[:n]
         for init in (0, 0xDEADBEEF, 0xFFFFFFFF):
             assert L.sgh_crc32(C.c_uint32(init), b, C.c_uint64(n)) == zlib.crc32(b, init), (n, init)
+
+
+# ---- the command line's argument forms (clap 4 derive over src/main.rs:54-108) — parsed only: `--dry-run-args` prints what the line
+# parsed to and exits before any file or device is touched
+def _dry(argv):
+    import json
+    import subprocess
+    from sgcount_amd import hostlib as HL
+    r = subprocess.run([HL.cli_path(), "--dry-run-args"] + argv, capture_output=True, text=True, timeout=60)
+    return r.returncode, (json.loads(r.stdout) if r.returncode == 0 else None), r.stderr
+
+
+CLI_ACCEPTED = [
+    # (argv, expected fields)
+    (["-l", "lib.fa", "-i", "a.fq", "b.fq", "--offset=5", "-xzq"],
+     {"library_path": "lib.fa", "input_paths": ["a.fq", "b.fq"], "offset": 5, "exact": True, "include_zero": True, "quiet": True}),
+    (["-l", "lib.fa", "-i", "a.fq", "-a5"], {"offset": 5, "exact": False}),
+    (["-l", "lib.fa", "-i", "a.fq", "-a=5"], {"offset": 5}),
+    (["-l", "lib.fa", "-i", "a.fq", "-xa", "5"], {"offset": 5, "exact": True}),
+    (["-l", "lib.fa", "-i", "a.fq", "-xa5", "-n", "s1"], {"offset": 5, "exact": True, "sample_names": ["s1"]}),
+    (["-llib.fa", "-ia.fq", "b.fq", "-t=4", "-prz"], {"library_path": "lib.fa", "input_paths": ["a.fq", "b.fq"], "threads": 4,
+                                                      "no_position_recursion": True, "reverse": True, "include_zero": True}),
+    (["--library-path=lib.fa", "--input-paths=a.fq", "b.fq", "-i", "c.fq"], {"input_paths": ["a.fq", "b.fq", "c.fq"]}),
+    (["--library-path", "lib.fa", "--input-paths", "a.fq", "--sample-names", "x", "--output-path=o.tsv", "--genemap", "g.txt",
+      "--subsample=100", "--threads", "2", "--no-position-recursion", "--reverse", "--exact", "--quiet", "--include-zero"],
+     {"sample_names": ["x"], "output_path": "o.tsv", "genemap": "g.txt", "subsample": 100, "threads": 2, "no_position_recursion": True,
+      "reverse": True, "exact": True, "quiet": True, "include_zero": True}),
+    (["-l", "lib.fa", "-i", "a.fq", "--"], {"input_paths": ["a.fq"]}),
+    (["-l", "lib.fa", "-i", "-", "-o", "-"], {"input_paths": ["-"], "output_path": "-"}),          # a lone dash is a value
+    (["-i", "a.fq", "-l", "lib.fa", "-n", "s", "-n", "t", "-i", "b.fq"], {"input_paths": ["a.fq", "b.fq"], "sample_names": ["s", "t"]}),
+    (["-l", "lib.fa", "-i", "a.fq", "--include-permutations"], {"exact": False}),                  # BASELINE.json's name for the default
+]
+CLI_REJECTED = [
+    # (argv, a piece of clap's message) — all exit with code 2
+    (["-l", "lib.fa", "-i", "a.fq", "--exact=1"], "unexpected value '1' for '--exact' found; no more were expected"),
+    (["-l", "lib.fa", "-i", "a.fq", "-x=1"], "unexpected value '1' for '--exact' found"),
+    (["-l", "lib.fa", "-i", "a.fq", "-x", "-x"], "the argument '--exact' cannot be used multiple times"),
+    (["-l", "lib.fa", "-l", "lib2.fa", "-i", "a"], "the argument '--library-path <LIBRARY_PATH>' cannot be used multiple times"),
+    (["-l", "lib.fa", "-i", "a.fq", "--", "extra"], "unexpected argument 'extra' found"),
+    (["-l", "lib.fa", "-i", "a.fq", "-a"], "a value is required for '--offset <OFFSET>' but none was supplied"),
+    (["-l", "lib.fa", "-i", "a.fq", "-a", "-x"], "a value is required for '--offset <OFFSET>' but none was supplied"),
+    (["-l", "lib.fa", "-i", "a.fq", "-a", "-5"], "unexpected argument '-5' found"),
+    (["-l", "lib.fa", "-i", "a.fq", "--bogus"], "unexpected argument '--bogus' found"),
+    (["-l", "lib.fa", "-i", "a.fq", "-xk"], "unexpected argument '-k' found"),
+    (["-l", "lib.fa", "-x", "-i"], "a value is required for '--input-paths <INPUT_PATHS>...' but none was supplied"),
+    (["-l", "lib.fa", "-i", "a.fq", "-a", "5x"], "invalid value '5x' for '--offset <OFFSET>': invalid digit found in string"),
+    (["-l", "lib.fa", "-i", "a.fq", "-t", ""], "invalid value '' for '--threads <THREADS>': cannot parse integer from empty string"),
+    (["stray", "-l", "lib.fa", "-i", "a"], "unexpected argument 'stray' found"),
+    (["-i", "a.fq"], "the following required arguments were not provided"),
+    (["-l", "lib.fa"], "--input-paths <INPUT_PATHS>..."),
+]
+
+
+@pytest.mark.parametrize("argv,want", CLI_ACCEPTED, ids=[" ".join(a) for a, _ in CLI_ACCEPTED])
+def test_cli_argument_forms_accepted(argv, want):
+    rc, got, err = _dry(argv)
+    assert rc == 0, err
+    for k, v in want.items():
+        assert got[k] == v, (k, got)
+
+
+@pytest.mark.parametrize("argv,msg", CLI_REJECTED, ids=[" ".join(a) for a, _ in CLI_REJECTED])
+def test_cli_argument_forms_rejected(argv, msg):
+    rc, _, err = _dry(argv)
+    assert rc == 2, (rc, err)
+    assert msg in err, err
+
+
+def test_cli_help_and_version_win():
+    import subprocess
+    from sgcount_amd import hostlib as HL
+    for argv in (["--help"], ["-l", "x", "-h", "--bogus-after-help-is-not-reached"][:3], ["-V"], ["-xV"]):
+        r = subprocess.run([HL.cli_path()] + argv, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and r.stdout, (argv, r.stderr)

@@ -34,7 +34,16 @@ def main():
     ap.add_argument("--notiming", action="store_true", help="leave the library's per-kernel events off (wall time only)")
     ap.add_argument("--opts", default="", help="extra options k=v,k=v applied to all variants")
     ap.add_argument("--lib-opts", default="", help="options k=v,k=v applied BEFORE the tables are built (align_slices, rest_filter, ...)")
+    ap.add_argument("--lib", choices=["ablate", "stamps"], default=None, help="load an experiment build of the library (sgcount_amd/build.py EXPERIMENT_SOS; built on the spot if stale)")
+    ap.add_argument("--lib-path", default=None, help="load this build of the library instead (an experiment .so under sgcount_amd/)")
     args = ap.parse_args()
+    if args.lib_path:
+        from sgcount_amd import _ffi, build as _b
+        _b.TARGETS.setdefault(os.path.abspath(args.lib_path), _b.TARGETS[_b.SO])
+        _ffi.load(os.path.abspath(args.lib_path))
+    if args.lib:
+        from sgcount_amd import _ffi, build as _b
+        _ffi.load(_b.EXPERIMENT_SOS[args.lib])
     import torch
     from sgcount_amd.workload import DeviceWorkload
     lib_opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in filter(None, args.lib_opts.split(","))}
@@ -56,7 +65,7 @@ def main():
         for v in variants:
             wl.dl.set_option("variant", specs[v][0])
             wl.dl.set_option("dbg", 0)
-            for k in ("cuckoo", "dense", "tag_sub", "direct", "six_byte", "five_byte", "balanced"):          # (place_trials is per context: --opts place_trials=1 turns the trials off)          # per-variant toggles start from their defaults
+            for k in ("cuckoo", "dense", "tag_sub", "direct", "six_byte", "five_byte", "balanced", "wide"):          # (place_trials is per context: --opts place_trials=1 turns the trials off)          # per-variant toggles start from their defaults
                 wl.dl.set_option(k, 1)
             for k, val in specs[v][1]:
                 wl.dl.set_option(k, int(val))
