@@ -154,7 +154,13 @@ static int fx_next(fx_iter *it, fx_record *r) {
     size_t n;
     const uint8_t *h = fx_line(it, &n);
     if (!h) return 0;
-    if (n == 0 && it->p >= it->end) return 0; /* trailing blank */
+    if (n == 0) {
+        /* blank lines at the very end are not records (any number of them); a blank line with anything behind it is a malformed header */
+        const uint8_t *q = it->p;
+        while (q < it->end && (*q == '\n' || *q == '\r')) q++;
+        if (q >= it->end) return 0;
+        return ORC_E_FORMAT;
+    }
     if (it->fmt == 0) {
         if (n && h[0] == '>') it->fmt = 1;
         else if (n && h[0] == '@') it->fmt = 2;
@@ -169,8 +175,10 @@ static int fx_next(fx_iter *it, fx_record *r) {
         size_t m;
         const uint8_t *plus = fx_line(it, &m);
         if (!plus || m == 0 || plus[0] != '+') return ORC_E_FORMAT;
-        const uint8_t *q = fx_line(it, &m);
-        if (!q) return ORC_E_FORMAT;
+        /* A stream that ends behind the separator line ends with a record whose quality line is empty: written with its terminator
+           ("+\n\n"), without it ("+\n") or not at all ("+") — no reader can tell those apart from a cut-off file, and fxread's choice is
+           not pinned here; decision #3 of DESIGN.md §2, shared with the product's readers (not a reference fact). */
+        (void)fx_line(it, &m);
     }
     return 1;
 }

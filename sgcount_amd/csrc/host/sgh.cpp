@@ -111,7 +111,9 @@ bool FastxReader::next(RecordView &r) {
     if (!get(1)) throw Panic("truncated FASTX record in " + s.path);
     if (s.fmt == 2) {
         if (!get(2) || l[2] == 0 || s.buf[o[2]] != '+') throw Panic("malformed FASTQ record in " + s.path);
-        if (!get(3)) throw Panic("truncated FASTQ record in " + s.path);
+        // a stream that ends behind the separator line ends with a record whose quality line is empty — written with its terminator
+        // ("+\n\n"), without it ("+\n") or not at all ("+"): the same bytes up to what no reader can tell apart (decision #3)
+        if (!get(3)) { o[3] = o[2] + l[2]; l[3] = 0; }
     }
     // a '\r' before the '\n' is part of the line terminator (CRLF files; fxread's behaviour is unpinned)
     for (int k = 0; k < 2; k++) if (l[k] && s.buf[o[k] + l[k] - 1] == '\r') l[k]--;
@@ -1037,7 +1039,8 @@ static bool count_fastq_text(sgc_sample *smp, const std::string &path, const Cou
         carry = tail;
         if (eof) break;
     }
-    if (first_line % 4 != 0) throw Panic("truncated FASTQ record in " + path);
+    // (3 mod 4: the stream ends behind a separator line — the last record's quality line is empty; reader decision #3)
+    if (first_line % 4 != 0 && first_line % 4 != 3) throw Panic("truncated FASTQ record in " + path);
     if (st) {
         st->text_bytes = feed.is_gz ? 0 : feed.file_size;
         st->reader_threads = feed.n_threads;
@@ -1248,6 +1251,7 @@ void count(const CountOptions &opt_in) {
     if (packable)
         for (size_t i = 0; i < std::min(n_workers, opt.input_paths.size()); i++)
             if (opt.offsets[i].index <= 0xFFFFFFFFull) scanners[i] = make_scanner(i);
+    const double t_before_runtime = now_s();                      // (what lies between t_lib and here is the scanners' start, not the runtime)
     int n_dev = n_dev_f.get();
     if (n_dev < 1) n_dev = 1;                                     // sgc_init below reports the missing device
     if (opt.max_devices > 0) n_dev = std::min(n_dev, (int)opt.max_devices);
@@ -1353,13 +1357,19 @@ void count(const CountOptions &opt_in) {
         if (!f) throw Error("cannot create the stats file: " + opt.stats_path);
         std::string per_dev;
         for (size_t d = 0; d < dev_build_s.size(); d++) { char b[48]; snprintf(b, sizeof(b), "%s%.6f", d ? ", " : "", dev_build_s[d]); per_dev += b; }
-        // setup_s: everything between the library and the first sample (scanners started, HIP runtime up, contexts, tables);
-        // hip_runtime_wait_s / device_init_s / table_build_s are its parts (the runtime comes up on its own thread from the start:
-        // what is reported is what the main thread still waited for)
-        fprintf(f, "{\"library_load_s\": %.6f, \"setup_s\": %.6f, \"hip_runtime_wait_s\": %.6f, \"table_build_s\": %.6f, \"samples_s\": %.6f, \"table_write_s\": %.6f, \"total_s\": %.6f, "
+        // setup_s: everything between the library and the first sample (scanners started, HIP runtime up, contexts, tables).  Its
+        // parts: scanner_start_s (the route filter of a hybrid library, the first scanners — for a .gz their constructor returns when
+        // the first chunk is inflated), hip_runtime_wait_s (the runtime comes up on a thread of its own from the start: what the main
+        // thread still waited for), then the devices side by side: device_init_s / table_build_s are those of the slowest device
+        // (init + build), table_build_per_device_s each device's build, contexts_ready_s all of it (the clones of the worker threads included)
+        size_t slowest = 0;
+        for (size_t d = 1; d < dev_build_s.size(); d++)
+            if (dev_init_s[d] + dev_build_s[d] > dev_init_s[slowest] + dev_build_s[slowest]) slowest = d;
+        const double slow_init = dev_init_s.empty() ? 0.0 : dev_init_s[slowest], slow_build = dev_build_s.empty() ? 0.0 : dev_build_s[slowest];
+        fprintf(f, "{\"library_load_s\": %.6f, \"setup_s\": %.6f, \"scanner_start_s\": %.6f, \"hip_runtime_wait_s\": %.6f, \"contexts_ready_s\": %.6f, \"table_build_s\": %.6f, \"samples_s\": %.6f, \"table_write_s\": %.6f, \"total_s\": %.6f, "
                    "\"device_init_s\": %.6f, \"context_free_s\": %.6f, \"count_entered_unix_s\": %.6f, \"stats_written_unix_s\": %.6f, "
                    "\"devices\": %d, \"contexts\": %zu, \"worker_threads\": %zu, \"table_build_per_device_s\": [%s], \"samples\": [",
-                t_lib - t_start, t_tables - t_lib, t_runtime - t_lib, std::max(0.0, t_tables - t_runtime - init_s), t_counted - t_tables, t_end - t_counted, t_end - t_start, init_s, t_freed - t_end, t_start_unix, unix_s(),
+                t_lib - t_start, t_tables - t_lib, t_before_runtime - t_lib, t_runtime - t_before_runtime, t_tables - t_runtime, slow_build, t_counted - t_tables, t_end - t_counted, t_end - t_start, slow_init, t_freed - t_end, t_start_unix, unix_s(),
                 n_dev, n_ctx, n_threads, per_dev.c_str());
         for (size_t i = 0; i < n; i++) {
             const SampleStats &x = stats[i];

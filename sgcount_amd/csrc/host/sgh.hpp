@@ -279,6 +279,7 @@ class FastqScanner {
     std::mutex mu;
     std::condition_variable cv;
     bool stop = false, failed = false, checked_end = false;
+    uint64_t gz_bad_line = 0;            // gzip input: the first line with a wrong marker byte — reported once the members' CRCs have been checked
     std::string error;
 };
 size_t usable_cpus();                                    // affinity mask capped by the cgroup CPU quota

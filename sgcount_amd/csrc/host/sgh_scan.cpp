@@ -173,6 +173,23 @@ struct FastqScanner::Block {
     std::vector<uint64_t> routed_offs;
 };
 
+// A BGZF member (bgzip, htslib: a gzip member whose extra field announces the member's size in a 'BC' subfield): its size in bytes
+// and the length of its extra field, or 0 if the `avail` bytes at `h` are not one whole such member.  One walk, with every bound,
+// for the pass that cuts the file into chunks of members and for the workers that inflate them.
+static size_t bgzf_member_size(const uint8_t *h, size_t avail, size_t &xlen) {
+    if (avail < 28 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return 0;
+    xlen = h[10] + 256u * h[11];
+    if (12 + xlen + 8 > avail) return 0;
+    size_t bsize = 0;
+    for (size_t x = 12; x + 4 <= 12 + xlen;) {
+        const size_t slen = h[x + 2] + 256u * h[x + 3];
+        if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2 && x + 6 <= 12 + xlen) bsize = (size_t)(h[x + 4] + 256u * h[x + 5]) + 1;
+        x += 4 + slen;
+    }
+    if (bsize < 12 + xlen + 8 || bsize > avail) return 0;
+    return bsize;
+}
+
 FastqScanner::FastqScanner(const std::string &path_, const ScanParams &prm_, size_t threads, size_t block_bytes, size_t max_ahead, int source_)
     : path(path_), prm(prm_) {
     source = source_;
@@ -206,17 +223,9 @@ FastqScanner::FastqScanner(const std::string &path_, const ScanParams &prm_, siz
             bool chain = true;
             std::vector<size_t> cuts(1, 0);
             while (chain && off < file_size) {
-                const uint8_t *h = map + off;
-                if (file_size - off < 28 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) { chain = false; break; }
-                const size_t xlen = h[10] + 256u * h[11];
-                if (12 + xlen + 8 > file_size - off) { chain = false; break; }
-                size_t bsize = 0;
-                for (size_t x = 12; x + 4 <= 12 + xlen;) {
-                    const size_t slen = h[x + 2] + 256u * h[x + 3];
-                    if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2 && x + 6 <= 12 + xlen) bsize = (size_t)(h[x + 4] + 256u * h[x + 5]) + 1;
-                    x += 4 + slen;
-                }
-                if (bsize < 12 + xlen + 8 || bsize > file_size - off) chain = false;
+                size_t xlen = 0;
+                const size_t bsize = bgzf_member_size(map + off, file_size - off, xlen);
+                if (bsize == 0) chain = false;
                 else {
                     off += bsize;
                     if (off - chunk_start >= gz_chunk_bytes && off < file_size) { cuts.push_back(off); chunk_start = off; }
@@ -374,16 +383,12 @@ void FastqScanner::run_gz() {
             if (bgzf_mode) {
                 // the members [bgzf_chunk_off[k], bgzf_chunk_off[k + 1]): sizes from the ISIZE trailers, then zlib, member by member
                 const size_t c_lo = bgzf_chunk_off[k], c_hi = bgzf_chunk_off[k + 1];
+                // (the same header walk as the one that cut the chunks, with the same bounds: a member whose size it cannot confirm here
+                // — the file changed under the mapping — is an error, never a read past the chunk)
                 auto bsize_of = [&](size_t off, size_t &xlen) {
-                    const uint8_t *h = map + off;
-                    xlen = h[10] + 256u * h[11];
-                    size_t bsize = 0;
-                    for (size_t x = 12; x + 4 <= 12 + xlen;) {
-                        const size_t slen = h[x + 2] + 256u * h[x + 3];
-                        if (h[x] == 'B' && h[x + 1] == 'C' && slen == 2) bsize = (size_t)(h[x + 4] + 256u * h[x + 5]) + 1;
-                        x += 4 + slen;
-                    }
-                    return bsize;
+                    const size_t bs = bgzf_member_size(map + off, c_hi - off, xlen);
+                    if (bs == 0) throw Error("corrupt BGZF member in " + path);
+                    return bs;
                 };
                 size_t total = 0;
                 for (size_t off = c_lo; off < c_hi;) {
@@ -394,9 +399,13 @@ void FastqScanner::run_gz() {
                 }
                 if (text_keep.size() < ROOM + total + 64) text_keep.resize(ROOM + total + 64 + (total >> 3));
                 txt = text_keep.data() + ROOM;
-                static thread_local z_stream zs;
-                static thread_local bool zs_ready = false;
-                if (!zs_ready) { memset(&zs, 0, sizeof zs); if (inflateInit2(&zs, -15) != Z_OK) throw Error("zlib: inflateInit2 failed"); zs_ready = true; }
+                struct RawInflater {                   // one per worker thread, released when the thread ends
+                    z_stream zs; bool ready = false;
+                    ~RawInflater() { if (ready) inflateEnd(&zs); }
+                };
+                static thread_local RawInflater inf;
+                if (!inf.ready) { memset(&inf.zs, 0, sizeof inf.zs); if (inflateInit2(&inf.zs, -15) != Z_OK) throw Error("zlib: inflateInit2 failed"); inf.ready = true; }
+                z_stream &zs = inf.zs;
                 size_t at = 0;
                 for (size_t off = c_lo; off < c_hi;) {
                     size_t xlen; const size_t bs = bsize_of(off, xlen);
@@ -690,8 +699,14 @@ bool FastqScanner::next(const uint64_t *&recs, size_t &n_records) {
                         }
                     }
             }
+            // a line with a wrong marker byte in text that passed its CRC is the sample's fault; in text that did not, the file's (above)
+            if (gz_bad_line)
+                throw Panic("malformed FASTQ record: line " + std::to_string(gz_bad_line) +
+                            " does not start with its marker byte ('@' header / '+' separator) in " + path);
             total_lines = lines_so_far;
-            if (lines_so_far % 4 != 0) throw Panic("truncated FASTQ record in " + path);
+            // (3 lines of a record: the stream ends behind its separator line — an empty quality line, written with its terminator
+            // ("+\n\n": cut off with the trailing blank lines), without it ("+\n"), or not at all ("+"); reader decision #3)
+            if (lines_so_far % 4 != 0 && lines_so_far % 4 != 3) throw Panic("truncated FASTQ record in " + path);
         }
         return false;
     }
@@ -699,6 +714,16 @@ bool FastqScanner::next(const uint64_t *&recs, size_t &n_records) {
     wait_s += scan_now_s() - t0;
     if (failed) throw Error(error);
     Block &blk = blocks[consumed];
+    if (blk.bad_line && gz_mode) {
+        // Compressed input: a damaged stream usually inflates to text that breaks the 4-line cycle long before the end of the member
+        // where its CRC is checked.  Whether to blame the sample (exit code 101, like the reference's reader) or the file ("corrupt
+        // gzip stream") is decided there: the blocks from here on are read to the end without handing out their records.
+        if (!gz_bad_line) gz_bad_line = blk.bad_line;
+    }
+    if (gz_bad_line) {
+        recs = blk.recs.data(); n_records = 0; routed_bytes = nullptr; routed_offs = nullptr; n_routed = 0;
+        return true;
+    }
     if (blk.bad_line)
         throw Panic("malformed FASTQ record: line " + std::to_string(blk.bad_line) +
                     " does not start with its marker byte ('@' header / '+' separator) in " + path);

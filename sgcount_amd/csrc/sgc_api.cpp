@@ -362,17 +362,22 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n, bool
             const int six = !direct ? 0 :
                             (c->five_byte && 2u * (c->L + 2u) - slice_bits <= 40u && slice_bits + (uint32_t)sub <= 2u * c->v_lib.core_cl) ? 2 :
                             (c->six_byte && 2u * (c->L + 2u) + 2u <= 48u) ? 1 : 0;
-            { timed t(c, T_PART); sgc_launch_part_k1(c->stream, s->d_err + 1, p, chunk, c->L, c->v_lib, tag_sub ? (uint32_t)sub : 0u, g, pool, desc, six, c->dbg, tot); }
+            // Every allocation of the pass BEFORE its first launch: k_partition adds its block counts into the per-slice totals, and a
+            // pass that gave up after it (out of memory for the run buffers) would leave them there for the next pass to add to.
+            sgc_core_geometry cg{};
+            size_t mrun_bytes = 0;
             if (core_path) {
-                // everything the slice probe does not settle (its misses + the generic partition) is resolved in LDS by the
-                // two core passes; k_count_slices itself lays those records out as pass A's runs
-                sgc_core_geometry cg;
                 sgc_core_plan(chunk, c->v_core[0], c->v_core[1], sgc_part_k2_grid(g) + (direct ? sgc_part_k2_direct_cols(g, bal) : 0u), &cg);
-                const size_t mrun_bytes = c->dense ? (size_t)g.pool_bytes << (direct ? (uint32_t)sub : 0u) : 0;
+                mrun_bytes = c->dense ? (size_t)g.pool_bytes << (direct ? (uint32_t)sub : 0u) : 0;
                 rc = ensure(&c->d_cbuf, &c->cbuf_cap, (size_t)(cg.runs_a_bytes + mrun_bytes + cg.fwd_bytes), c->device, c->vmm_runs ? c->vmm_chunk : 0);
                 if (rc) return rc;
                 rc = ensure(&c->d_csmall, &c->csmall_cap, cg.small_bytes);
                 if (rc) return rc;
+            }
+            { timed t(c, T_PART); sgc_launch_part_k1(c->stream, s->d_err + 1, p, chunk, c->L, c->v_lib, tag_sub ? (uint32_t)sub : 0u, g, pool, desc, six, c->dbg, tot); }
+            if (core_path) {
+                // everything the slice probe does not settle (its misses + the generic partition) is resolved in LDS by the
+                // two core passes; k_count_slices itself lays those records out as pass A's runs
                 if (direct && c->place_trials > 1 && chunk >= (1ull << 25) && c->placed_pool != c->d_pool) {
                     // Placement trials.  K1 and K2 speed up and slow down TOGETHER from candidate to candidate (K1 0.30 ... 0.36 ms,
                     // K2 0.24 ... 0.31), and K1 touches nothing of ours but the pool: it is the pool's place in memory that decides.
@@ -1434,7 +1439,8 @@ int sgc_sample_push_fastq(sgc_sample *s, const uint8_t *text, uint64_t n_bytes, 
     uint64_t lines = 0;
     const int rc = push_fastq_part(s, text, n_bytes, where, 0, UINT64_MAX, UINT64_MAX, n_records_out, &lines);
     if (rc) return rc;
-    if (lines % 4 != 0)
+    // (3 mod 4: the text ends behind a separator line — its last record has an empty quality line; DESIGN.md §2, reader decision #3)
+    if (lines % 4 != 0 && lines % 4 != 3)
         return fail(SGC_E_ARG, "sgc_sample_push_fastq: the chunk does not hold whole 4-line records (" +
                                    std::to_string(lines) + " lines)");
     return SGC_OK;

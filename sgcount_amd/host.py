@@ -66,7 +66,9 @@ class Record:
 
 
 def parse_fastx(text: bytes):
-    """Yields Records from FASTA ('>' two-line) or FASTQ ('@' four-line) text."""
+    """Yields Records from FASTA ('>' two-line) or FASTQ ('@' four-line) text.  The reader decisions of DESIGN.md §2 (fxread is not
+    pinned here): a '\r' before the '\n' belongs to the terminator; blank lines at the very end are not records; a FASTQ stream
+    that ends behind a separator line ends with a record whose quality line is empty (written "+\n\n", "+\n" or "+")."""
     if not text:
         return
     lines = text.split(b"\n")
@@ -79,12 +81,22 @@ def parse_fastx(text: bytes):
         step, marker = 4, b"@"
     else:
         raise ValueError("not FASTA/FASTQ: first byte is %r" % text[:1])
-    if len(lines) % step:
-        raise ValueError("truncated FASTX record")
-    for i in range(0, len(lines), step):
+    i, n = 0, len(lines)
+    while i < n:
+        if lines[i] == b"":
+            if any(lines[i:]):
+                raise ValueError("malformed FASTX header at line %d" % (i + 1))
+            return                                  # only blank lines are left
         if lines[i][:1] != marker:
             raise ValueError("malformed FASTX header at line %d" % (i + 1))
+        if i + 1 >= n:
+            raise ValueError("truncated FASTX record")
+        if step == 4:
+            if i + 2 >= n or lines[i + 2][:1] != b"+":
+                raise ValueError("malformed FASTQ record at line %d" % (i + 3))
+            # (i + 3 >= n: the stream ends behind the separator line — an empty quality line)
         yield Record(lines[i][1:], lines[i + 1])
+        i += step
 
 
 def read_path(path: str) -> bytes:

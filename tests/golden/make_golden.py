@@ -11,6 +11,8 @@ tests/test_oracle_fixtures.py).
 Outputs
   example_counts.json   per example FASTQ x {exact, 1mm} x {recursion on/off}: counts (library order), total, matched
   edge_cases.json       small hand-made + seeded-random cases with per-read assignments
+  fastq_endings.json    how a FASTQ stream may end (reader decision #3): the tail behind a body of whole records,
+                        and what the count of the whole text must be — or that it must be refused
 Run:  python tests/golden/make_golden.py
 """
 import gzip
@@ -198,7 +200,35 @@ def edge_cases():
     return cases
 
 
+FASTQ_ENDING_TAILS = [
+    "@e\n\n+\n\n", "@e\n\n+\n", "@e\n\n+", "@e\n\n+\n\n\n\n", "@e\r\n\r\n+\r\n", "@e\r\n\r\n+\r\n\r\n",
+    "@e\nTTGATTACGG\n+\n", "@e\nTTGATTACGG\n+", "@e\nTTGATTACGG\n+\nIIIIIIIIII", "\n\n\n", "",
+    "@e\n\n", "@e\n", "@e", "@e\nTTGATTACGG\n", "@e\nTTGATTACGG\nIIIIIIIIII\n+\n",
+]
+
+
+def fastq_endings():
+    """A body of whole records + a tail.  A stream that ends behind a separator line ends with a record whose quality line is empty;
+    blank lines at the very end are not records; every other incomplete tail is refused."""
+    rng = random.Random(20261005)
+    guides = ["ACGTAC", "ACGTAG", "TTGCAA", "TTGGTA", "CCCCCC", "GATTAC"]
+    lib_text = "".join(">g%d\n%s\n" % (i, g) for i, g in enumerate(guides)).encode()
+    body = "".join("@r%d\nTT%sGG\n+\n%s\n" % (i, rng.choice(guides), "I" * 10) for i in range(200))
+    out = {"library": lib_text.decode(), "offset": 2, "body": body, "cases": []}
+    for tail in FASTQ_ENDING_TAILS:
+        text = (body + tail).encode()
+        try:
+            counts, tot, mat = O.count_text(lib_text, text, False, 2, False, True)
+            out["cases"].append({"tail": tail, "counts": counts, "total": tot, "matched": mat})
+        except Exception:
+            out["cases"].append({"tail": tail, "error": True})
+    return out
+
+
 def main():
+    with open(os.path.join(HERE, "fastq_endings.json"), "w") as f:
+        json.dump(fastq_endings(), f, separators=(",", ":"))
+        f.write("\n")
     with open(os.path.join(HERE, "example_counts.json"), "w") as f:
         json.dump(example_counts(), f, separators=(",", ":"))
         f.write("\n")

@@ -267,3 +267,36 @@ def test_malformed_fastq_panics_like_the_reference(cli, tmp_path, example_reads)
             rc, out, err = run(cli, "-l", LIB, "-i", p, "-a", "5", "-q", "--pack", pack)
             assert rc == 101, (name, pack, rc, err)
             assert "panicked" in err
+
+
+@pytest.mark.parametrize("kind", ["plain", "gz", "bgzf"])
+def test_fastq_endings_golden(cli, tmp_path, kind):
+    """How a FASTQ stream may end (reader decision #3; tests/golden/fastq_endings.json, generated from the oracle): a
+    stream that ends behind a separator line ends with a record whose quality line is empty; blank lines at the very end are not
+    records; every other incomplete tail is refused with the reference's panic exit code — through every reader of the command
+    line (--pack scan / fastq / device / host), on plain text, one gzip stream and BGZF."""
+    import json
+    from sgcount_amd import bgzf
+    g = json.load(open(os.path.join(os.path.dirname(DATA), "golden", "fastq_endings.json")))
+    lib = os.path.join(str(tmp_path), "lib.fa")
+    open(lib, "w").write(g["library"])
+    ids = [ln[1:] for ln in g["library"].split("\n") if ln.startswith(">")]
+    good, bad = [], []
+    for k, c in enumerate(g["cases"]):
+        text = (g["body"] + c["tail"]).encode()
+        p = os.path.join(str(tmp_path), "c%02d.fastq%s" % (k, "" if kind == "plain" else ".gz"))
+        open(p, "wb").write(text if kind == "plain" else gzip.compress(text) if kind == "gz" else bgzf.bgzf_bytes(text, block=700))
+        (bad if c.get("error") else good).append((p, c))
+    names = ["s%d" % i for i in range(len(good))]
+    want = "Guide\t" + "\t".join(names) + "\n" + "".join(
+        "%s\t%s\n" % (ident, "\t".join(str(c["counts"][j]) for _, c in good)) for j, ident in enumerate(ids) if any(c["counts"][j] for _, c in good))
+    for pack in ("scan", "fastq", "device", "host"):
+        rc, out, err = run(cli, "-l", lib, "-i", *[p for p, _ in good], "-n", *names, "-a", str(g["offset"]), "--pack", pack)
+        assert rc == 0, (kind, pack, err)
+        assert out == want, (kind, pack)
+        for (p, c), name in zip(good, names):
+            assert "Finished: %s; Fraction mapped: %.3f [%d / %d]" % (name, c["matched"] / c["total"], c["matched"], c["total"]) in err, (kind, pack, name, err)
+    for pack in ("scan", "fastq", "host"):
+        for p, c in bad:
+            rc, out, err = run(cli, "-l", lib, "-i", p, "-a", str(g["offset"]), "-q", "--pack", pack)
+            assert rc == 101 and "panicked" in err, (kind, pack, c["tail"], rc, err)

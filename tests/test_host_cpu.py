@@ -392,6 +392,17 @@ def test_scanner_packs_a_gzip_stream_like_its_text(tmp_path):
     (tmp_path / "trunc.gz").write_bytes(good[: len(good) * 2 // 3])
     with pytest.raises(hostlib.HostError):
         hostlib.scan_records(str(tmp_path / "trunc.gz"), 20, threads=3, block_bytes=1 << 16, cap=len(seqs) + 16)
+    # a damaged FILE is never blamed on the sample: text that breaks the 4-line cycle is reported as a malformed record (code 101)
+    # only once the member's CRC has vouched for it
+    for seed in range(24):
+        r2 = random.Random(seed)
+        bad = bytearray(good)
+        for _ in range(r2.choice([1, 1, 3])):
+            bad[r2.randrange(20, len(bad) - 8)] ^= 1 << r2.randrange(8)
+        (tmp_path / "flip.gz").write_bytes(bytes(bad))
+        with pytest.raises(hostlib.HostError) as e:
+            hostlib.scan_records(str(tmp_path / "flip.gz"), 20, threads=3, block_bytes=1 << 15, cap=len(seqs) + 16)
+        assert e.value.code == 1, (seed, str(e.value))
     lines = fastq(b"\n").split(b"\n")
     mal = list(lines); mal[4 * 700 + 2] = b"-"
     (tmp_path / "mal.gz").write_bytes(gzip.compress(b"\n".join(mal)))
@@ -576,3 +587,48 @@ def test_cli_help_and_version_win():
     for argv in (["--help"], ["-l", "x", "-h", "--bogus-after-help-is-not-reached"][:3], ["-V"], ["-xV"]):
         r = subprocess.run([HL.cli_path()] + argv, capture_output=True, text=True, timeout=60)
         assert r.returncode == 0 and r.stdout, (argv, r.stderr)
+
+
+# ---- reader decision #3: a FASTQ stream that ends behind a separator line ends with a record whose quality line is empty
+LAST_RECORD_TAILS = [
+    # (what follows 50 whole records, records expected (None = an error), why)
+    (b"@e\n\n+\n\n", 51), (b"@e\n\n+\n", 51), (b"@e\n\n+", 51), (b"@e\n\n+\n\n\n\n", 51), (b"@e\r\n\r\n+\r\n", 51), (b"@e\r\n\r\n+\r\n\r\n", 51),
+    (b"@e\nACGTACGTAC\n+\n", 51), (b"@e\nACGTACGTAC\n+", 51),
+    (b"\n\n\n", 50), (b"", 50),
+    (b"@e\n\n", None), (b"@e\n", None), (b"@e", None), (b"@e\nACGT\n", None),
+]
+
+
+@pytest.mark.parametrize("tail,want", LAST_RECORD_TAILS, ids=[repr(t) for t, _ in LAST_RECORD_TAILS])
+def test_last_record_with_an_empty_quality_line(tmp_path, tail, want):
+    """Every reader takes the same decision on how a FASTQ stream may end: the oracle (fx_next), the Python mirror (parse_fastx), the
+    record reader (FastxReader), and the scanner on plain text, one gzip stream and BGZF.  (fxread's own behaviour is unpinned:
+    SURVEY §8c; the GPU text parser takes the same decision in tests/test_ingest_gpu.py.)"""
+    import gzip
+    from sgcount_amd import hostlib, host as S, bgzf
+    text = b"".join(b"@r%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(50)) + tail
+    lib = b">g\nACGTACGTAC\n"
+    paths = {"plain": tmp_path / "s.fastq", "gz": tmp_path / "s.fastq.gz", "bgzf": tmp_path / "b.fastq.gz"}
+    paths["plain"].write_bytes(text)
+    paths["gz"].write_bytes(gzip.compress(text))
+    paths["bgzf"].write_bytes(bgzf.bgzf_bytes(text, block=300))
+    if want is None:
+        with pytest.raises(Exception):
+            O.count_text(lib, text, False, 0, True, True)
+        with pytest.raises(ValueError):
+            list(S.parse_fastx(text))
+        for p in paths.values():
+            with pytest.raises(hostlib.HostError) as e:
+                hostlib.fastx_stats(str(p))
+            assert e.value.code == 101
+            with pytest.raises(hostlib.HostError) as e:
+                hostlib.scan_records(str(p), 10, threads=2, block_bytes=4096)
+            assert e.value.code == 101
+        return
+    _, total, matched = O.count_text(lib, text, False, 0, True, True)
+    assert total == want and matched == 50 + (1 if b"ACGTACGTAC" in tail else 0)
+    assert len(list(S.parse_fastx(text))) == want
+    for kind, p in paths.items():
+        assert hostlib.fastx_stats(str(p))[0] == want, kind
+        got, lines = hostlib.scan_records(str(p), 10, threads=2, block_bytes=4096)
+        assert len(got) == want, kind

@@ -215,3 +215,48 @@ def test_offset_beyond_the_staged_halo(env, reverse):
     dl.set_stream(torch.cuda.current_stream().cuda_stream)
     assert _count_parts(torch, S, dl, [text], reverse, o, True, ffi.MEM_DEVICE) == want
     assert _count_parts(torch, S, dl, _cut_at_lines(text, rng, 6), reverse, o, True, ffi.MEM_HOST) == want
+
+
+def test_a_stream_may_end_behind_a_separator_line(env):
+    """Reader decision #3 (tests/golden/fastq_endings.json): the last record's quality line may be empty and unterminated.
+    The whole-text entry point takes such a text (3 lines of a record at its end), the part-wise one counts its sequence line."""
+    import json
+    import os
+    torch, S, synth, workload = env
+    ffi = S._ffi
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fastq_endings.json")))
+    library = S.Library.from_reader(S.parse_fastx(g["library"].encode()))
+    dl = library.device(True)
+    dl.set_stream(torch.cuda.current_stream().cuda_stream)
+    for c in g["cases"]:
+        text = (g["body"] + c["tail"]).encode()
+        while text.endswith(b"\n\n"):                 # blank lines at the very end are the host's to cut (TextFeeder, FastqScanner)
+            text = text[:-1]
+        lines = text.count(b"\n") + (0 if text.endswith(b"\n") else 1)
+        if c.get("error"):
+            # 1 or 2 lines of a record at the end: the push refuses the text; a whole number of lines with a wrong marker byte: the finish does
+            smp = C.c_void_p()
+            ffi.check(dl.lib.sgc_sample_begin(dl.ctx, C.byref(smp), 0, g["offset"], 1))
+            buf = C.create_string_buffer(text, len(text))
+            rc_push = dl.lib.sgc_sample_push_fastq(smp, buf, len(text), ffi.MEM_HOST, None)
+            out = np.zeros(len(library), dtype=np.uint64)
+            t, m = C.c_uint64(), C.c_uint64()
+            rc_fin = dl.lib.sgc_sample_finish(smp, out.ctypes.data, C.byref(t), C.byref(m))
+            assert (rc_push != 0) == (lines % 4 in (1, 2)) and (rc_push != 0 or rc_fin == ffi.E_FORMAT), (c["tail"], rc_push, rc_fin)
+            dl.lib.sgc_sample_free(smp)
+            continue
+        want = (c["counts"], c["total"], c["matched"])
+        assert _count_parts(torch, S, dl, [text], False, g["offset"], True, ffi.MEM_DEVICE) == want, c["tail"]
+        assert _count_parts(torch, S, dl, _cut_at_lines(text, random.Random(5), 7), False, g["offset"], True, ffi.MEM_HOST) == want, c["tail"]
+        smp = C.c_void_p()
+        ffi.check(dl.lib.sgc_sample_begin(dl.ctx, C.byref(smp), 0, g["offset"], 1))
+        try:
+            buf = C.create_string_buffer(text, len(text))
+            nrec = C.c_uint64(0)
+            ffi.check(dl.lib.sgc_sample_push_fastq(smp, buf, len(text), ffi.MEM_HOST, C.byref(nrec)))
+            out = np.zeros(len(library), dtype=np.uint64)
+            t, m = C.c_uint64(), C.c_uint64()
+            ffi.check(dl.lib.sgc_sample_finish(smp, out.ctypes.data, C.byref(t), C.byref(m)))
+            assert (out.tolist(), t.value, m.value) == want and nrec.value == c["total"], c["tail"]
+        finally:
+            dl.lib.sgc_sample_free(smp)

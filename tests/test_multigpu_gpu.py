@@ -110,11 +110,12 @@ def test_cli_workers_on_one_device_share_one_table_set(tmp_path):
         assert p.returncode == 0, p.stderr.decode()
         return json.load(open(stats))
     run(1)                                             # warm the page cache / the device
-    one = min((run(1) for _ in range(2)), key=lambda s: s["table_build_s"])
-    four = min((run(4) for _ in range(2)), key=lambda s: s["table_build_s"])
+    one = min((run(1) for _ in range(2)), key=lambda s: s["contexts_ready_s"])
+    four = min((run(4) for _ in range(2)), key=lambda s: s["contexts_ready_s"])
     assert one["contexts"] == 1 and four["contexts"] == 4 and four["devices"] == 1
     assert len(four["table_build_per_device_s"]) == 1
-    assert four["table_build_s"] < 1.5 * one["table_build_s"] + 0.05, (one["table_build_s"], four["table_build_s"])
+    # (contexts_ready_s: device init + table build + the clones of the other worker threads; table_build_s alone is one device's build)
+    assert four["contexts_ready_s"] < 1.5 * one["contexts_ready_s"] + 0.05, (one["contexts_ready_s"], four["contexts_ready_s"])
     rows = [ln.split("\t") for ln in open(out).read().splitlines()[1:]]
     got = {r[0]: [int(x) for x in r[1:]] for r in rows}
     want0, _, _ = O.count_text(lib_text, texts[0], False, 30, False, True)

@@ -229,7 +229,7 @@ def test_fastq_ingest_on_device(env, L, reverse, recursion):
     smp = C.c_void_p()
     ffi.check(dl.lib.sgc_sample_begin(dl.ctx, C.byref(smp), 0, 30, 1))
     bad = text[: text.index(b"\n", 5000) + 1]
-    if bad.count(b"\n") % 4 == 0:
+    while bad.count(b"\n") % 4 in (0, 3):       # (3 lines of a record at the end are a record with an empty quality line: DESIGN.md §2, decision #3)
         bad = bad[: bad.rindex(b"\n", 0, len(bad) - 1) + 1]
     assert dl.lib.sgc_sample_push_fastq(smp, bad, len(bad), ffi.MEM_HOST, None) == ffi.E_ARG
     dl.lib.sgc_sample_free(smp)
