@@ -45,6 +45,17 @@ NEEDED_BYTES = 8.0              # what the shipped path needs per read: one pack
 FASTQ_BYTES_PER_READ = 316.0    # text of one synthetic record
 
 
+def kernel_sources_sha16():
+    """identifies the device code the PMC traffic figures of profiles/pmc_traffic.json belong to"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "sgcount_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "sgc_*.h"))):
+        h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,6 +71,8 @@ def parse_args(argv=None):
     ap.add_argument("--e2e-dir", default=None, help="where the FASTQ text is written (default: /dev/shm or /tmp)")
     ap.add_argument("--dominant", type=int, default=40, help="percent of the reads of the skewed-sample leg that draw ONE guide; 0 disables the leg")
     ap.add_argument("--placement-trials", type=int, default=1, help="0: skip the second timed region that prices the opt-in placement trials (profiling runs)")
+    ap.add_argument("--other-configs", type=int, default=1, help="0: skip the short legs on BASELINE.json configs[1] (exact) and configs[3] (auto-offset)")
+    ap.add_argument("--multi-sample-reads", type=int, default=25_000_000, help="reads per sample of the multi-sample end-to-end leg (4 samples at N = 1, N at N > 1 through ONE command line); 0 disables it")
     return ap.parse_args(argv)
 
 
@@ -121,13 +134,13 @@ def cpu_baseline(lib_seqs, L, offset, exact, recursion, seed, mode, budget_s):
     base = {"value": done / spent, "unit": "reads/s", "cores": 1, "kind": "port",
             "sample": "first %d reads of the same synthetic sample as FASTQ text in memory (%.1f s of CPU; one-time "
                       "library%s setup %.1f s excluded)" % (done, spent, "" if exact else "+permuter", setup_s),
-            "setup_s": setup_s, "host_cpus": os.cpu_count(),
+            "setup_s": setup_s, "host_cpus": os.cpu_count(), "host_cpus_usable": len(os.sched_getaffinity(0)), "host_cpus_cgroup_quota": _cpu_quota(),
             # probe for the real thing — expected absent (no Rust toolchain, no crates mirror)
             "reference_binary": shutil.which("sgcount"), "cargo": shutil.which("cargo")}
     # courtesy line: the same port on N threads (ctypes releases the GIL), every thread its own Counter over its own chunks
     try:
         from concurrent.futures import ThreadPoolExecutor
-        threads = max(1, min(16, (os.cpu_count() or 1)))
+        threads = max(1, min(16, len(os.sched_getaffinity(0))))
         per_thread = 2
         texts = [[synth.fastq_host(lib_seqs, (t * per_thread + k) * chunk, chunk, seed, mode) for k in range(per_thread)]
                  for t in range(threads)]
@@ -204,6 +217,171 @@ def write_fastq(wl, n, path, chunk=2_000_000):
         for first in range(0, n, chunk):
             m = min(chunk, n - first)
             text, _ = synth.fastq_device(wl.lib_dev, first, m, wl.reads_seed, wl.mode)
+            if pinned is None or pinned.numel() < text.numel():
+                pinned = torch.empty(int(text.numel() * 1.05), dtype=torch.uint8, pin_memory=True)
+            pinned[: text.numel()].copy_(text)
+            torch.cuda.synchronize()
+            f.write(memoryview(pinned.numpy())[: text.numel()])
+            del text
+    del pinned
+
+
+def _cpu_quota():
+    """CPUs the cgroup grants this process (cpu.max quota / period), or None: the affinity mask of a GPU box shows every core of the host"""
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                return None if txt[0] == "max" else float(txt[0]) / float(txt[1])
+            q = float(txt[0])
+            return None if q <= 0 else q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        except (OSError, ValueError, IndexError):
+            continue
+    return None
+
+
+def _fractions(reads, steps, kernel_ms, algo_bytes):
+    """both byte accountings of DESIGN.md §6 for one timed region"""
+    a = algo_bytes * reads * steps / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
+    n = NEEDED_BYTES * reads * steps / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
+    return {"achieved_GBps": a, "frac": a / HBM_PEAK_GBPS if a else None, "algorithmic_bytes_per_read": algo_bytes,
+            "achieved_on_needed_bytes_GBps": n, "frac_on_needed_bytes": n / HBM_PEAK_GBPS if n else None}
+
+
+def _short_leg(wl, steps, warmup, algo_bytes):
+    """`steps` passes over wl's resident sample, timed like the headline (wall clock around synchronised steps + the library's per-kernel events)"""
+    import torch
+    for _ in range(warmup):
+        wl.step()
+    torch.cuda.synchronize()
+    wl.dl.timing(True)
+    wl.dl.timing(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    tm = wl.dl.timing(reset=True)
+    wl.dl.timing(False)
+    kernel_ms = tm.part_ms + tm.lookup_ms + tm.miss_ms + tm.hist_ms
+    counts, total, matched = wl.result()
+    assert total == wl.n_reads and int(counts.sum()) == matched, "count-sum invariant violated"
+    return {"steps": steps, "ms_per_step": 1e3 * el / steps, "value": wl.n_reads * steps / el, "unit": "reads/s",
+            "kernel_ms_per_step": kernel_ms / steps,
+            "kernels": {"partition_ms_per_step": tm.part_ms / steps, "slice_count_ms_per_step": tm.lookup_ms / steps,
+                        "miss_resolve_ms_per_step": tm.miss_ms / steps, "histogram_ms_per_step": tm.hist_ms / steps},
+            "roofline": _fractions(wl.n_reads, steps, kernel_ms, algo_bytes), "matched_fraction": matched / total}
+
+
+def other_configs(args, exact_headline, L, offset, recursion, dev_index):
+    """BASELINE.json's other 1-GPU configurations, each as a short leg of its own resident sample (5 steps, outside the headline's
+    timed region): configs[1] -x (or configs[2] when the headline itself is -x) and configs[3], the variable-adapter sample whose
+    offset the offsetter has to find first (src/main.rs:163-176 -> src/offsetter.rs:185-210) — its wall time on the 5000-read head
+    of the sample's own FASTQ text is reported beside the pass."""
+    import tempfile
+    from sgcount_amd import hostlib, synth
+    from sgcount_amd.workload import DeviceWorkload
+    out = {}
+    steps, warmup = 5, 2
+    other_exact = not exact_headline
+    wl = DeviceWorkload(args.reads, args.guides, L, one_mismatch=not other_exact, position_recursion=recursion, offset=offset,
+                        reads_seed=synth.READS_SEED, device_index=dev_index)
+    try:
+        leg = _short_leg(wl, steps, warmup, ALGO_BYTES["exact" if other_exact else "1mm"])
+        leg["workload"] = "BASELINE.json configs[%d]: same library and reads, %s" % (1 if other_exact else 2, "-x exact only" if other_exact else "exact + 1 mismatch")
+        out["configs[%d]" % (1 if other_exact else 2)] = leg
+    finally:
+        wl.close()
+    del wl
+    # configs[3]: adapter length drawn from {28..32}; no -a: the offsetter reads the library and the first 5000 reads
+    wl = DeviceWorkload(args.reads, args.guides, L, one_mismatch=not exact_headline, position_recursion=recursion, offset=offset,
+                        reads_seed=synth.READS_SEED, device_index=dev_index, mode=synth.MODE_STAGGER)
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            lp, fp = os.path.join(d, "library.fa"), os.path.join(d, "head.fastq")
+            open(lp, "wb").write(synth.library_fasta(wl.lib_seqs))
+            open(fp, "wb").write(synth.fastq_host(wl.lib_seqs, 0, 6000, synth.READS_SEED, synth.MODE_STAGGER))
+            hostlib.entropy_offset_group(lp, [fp], 5000)            # (first call: the library file enters the page cache)
+            t0 = time.perf_counter()
+            (rev, idx), = hostlib.entropy_offset_group(lp, [fp], 5000)
+            off_s = time.perf_counter() - t0
+        leg = _short_leg(wl, steps, warmup, ALGO_BYTES["exact" if exact_headline else "1mm"])
+        leg["workload"] = ("BASELINE.json configs[3]: adapter of 28..32 bases (5/10/70/10/5 %), no -a; the records were packed at the offset the "
+                           "offsetter must find; reads behind a 28- or 32-base adapter stay unmatched (src/counter.rs:96-140 tries +-1 only)")
+        leg["offsetter"] = {"found": ("Reverse(%d)" if rev else "Forward(%d)") % idx, "expected": "Forward(%d)" % offset, "ok": (not rev) and idx == offset,
+                            "wall_s": off_s, "reads_sampled": 5000, "note": "host f64 over the library (100k guides) + the 5000-read head: src/offsetter.rs:185-210"}
+        out["configs[3]"] = leg
+    finally:
+        wl.close()
+    return out
+
+
+
+def multi_sample_leg(wl, args, exact, n_devices, where, want=None):
+    """BASELINE.json configs[4] the way the reference runs it (src/main.rs:98-99,145, src/count.rs:117-136): S input files through
+    ONE command line with -t S — here S = 4 samples on the one GPU at N = 1, S = N samples dealt to N devices at N > 1.  The files
+    are consecutive quarters of the bench sample, so at N = 1 the columns must add up to the resident pass's table."""
+    import numpy as np
+    from sgcount_amd import hostlib, synth
+    S = 4 if n_devices == 1 else n_devices
+    per = int(args.multi_sample_reads)
+    if per * S > args.reads:
+        per = args.reads // S
+    need = per * S * FASTQ_BYTES_PER_READ * 1.05
+    avail = _mem_available()
+    if _free_bytes(where) < need * 1.05 or (avail and avail < need * 1.5):
+        return {"skipped": "no room for %d x %dM reads of FASTQ text under %s" % (S, per // 1_000_000, where)}
+    d = os.path.join(where, "sgc_multi_%d" % os.getpid())
+    os.makedirs(d, exist_ok=True)
+    try:
+        lib_path, table, stats = os.path.join(d, "library.fa"), os.path.join(d, "table.tsv"), os.path.join(d, "stats.json")
+        open(lib_path, "wb").write(synth.library_fasta(wl.lib_seqs))
+        t0 = time.perf_counter()
+        paths = []
+        for k in range(S):
+            fp = os.path.join(d, "s%d.fastq" % k)
+            pinned_write_range(wl, k * per, per, fp)
+            paths.append(fp)
+        write_s = time.perf_counter() - t0
+        cli = hostlib.cli_path()
+        argv = ["-l", lib_path, "-i"] + paths + ["-a", "30", "-q", "-o", table, "-t", str(S), "--devices", str(n_devices)] + (["-x"] if exact else [])
+        runs = [_run_cli(cli, argv, stats=stats) for _ in range(2)]
+        wall, st = min(runs, key=lambda r: r[0])
+        cols = np.zeros((S, args.guides), dtype=np.uint64)
+        with open(table, "rb") as f:
+            next(f)
+            for line in f:
+                cells = line.rstrip(b"\n").split(b"\t")
+                cols[:, int(cells[0][2:])] = [int(c) for c in cells[1:]]
+        smp = st["samples"]
+        out = {"samples": S, "reads_per_sample": per, "devices": n_devices, "worker_threads": st.get("worker_threads"), "contexts": st.get("contexts"),
+               "wall_s": wall, "wall_s_all_runs": [r[0] for r in runs], "reads_per_s": S * per / wall,
+               "sample_s": [x["wall_s"] for x in smp], "sample_device": [x.get("device") for x in smp],
+               "scanner_threads_per_sample": [x["reader_threads"] for x in smp],
+               "scanner_busy_s_sum_over_threads": [x["read_busy_s"] for x in smp],
+               "scanner_busy_s_all_samples": sum(x["read_busy_s"] for x in smp),
+               "host_cpus_usable": len(os.sched_getaffinity(0)), "host_cpus_online": os.cpu_count(), "host_cpus_cgroup_quota": _cpu_quota(),
+               "samples_s": st.get("samples_s"), "setup_s": st.get("setup_s"), "table_build_per_device_s": st.get("table_build_per_device_s"),
+               "fastq_write_s": write_s, "reads_counted": [int(x["reads"]) for x in smp],
+               "command": "sgcount-hip -l library.fa -i s0.fastq .. s%d.fastq -a 30 -t %d --devices %d" % (S - 1, S, n_devices),
+               "note": "every sample is scanned by its own scanner threads (all samples share the host's usable CPUs: --scan-threads defaults to "
+                       "min(16, cpus - 1) / worker threads) — the aggregate is bound by the host's scan of the text, not by the GPU(s)"}
+        if want is not None and per * S == args.reads:
+            out["columns_add_up_to_the_resident_pass"] = bool(np.array_equal(cols.sum(axis=0), want))
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def pinned_write_range(wl, first, n, path, chunk=2_000_000):
+    """reads [first, first + n) of the workload's sample as FASTQ text"""
+    import torch
+    from sgcount_amd import synth
+    pinned = None
+    with open(path, "wb", buffering=0) as f:
+        for a in range(first, first + n, chunk):
+            m = min(chunk, first + n - a)
+            text, _ = synth.fastq_device(wl.lib_dev, a, m, wl.reads_seed, wl.mode)
             if pinned is None or pinned.numel() < text.numel():
                 pinned = torch.empty(int(text.numel() * 1.05), dtype=torch.uint8, pin_memory=True)
             pinned[: text.numel()].copy_(text)
@@ -458,6 +636,13 @@ def e2e_block(wl, args, exact, cpu):
                                                   "process start-up and the one-time table build")
     finally:
         shutil.rmtree(d, ignore_errors=True)
+    if args.multi_sample_reads > 0:
+        try:                                      # (the single sample's text is gone by now: the four files take its place)
+            wl.step()
+            want_all, _, _ = wl.result()
+            out["multi_sample"] = multi_sample_leg(wl, args, exact, 1, where, want_all)
+        except Exception as e:
+            out["multi_sample"] = {"error": repr(e)[:500]}
     return out
 
 
@@ -662,9 +847,16 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc) and args.reads == 100_000_000 and args.guides == 100_000:
             try:
-                d = json.load(open(pmc)).get(args.workload)
-                traffic = d["hbm_bytes_per_step"]
-                traffic_note = "%.1f HBM B/read measured (%s) vs %.0f algorithmic" % (d["bytes_per_read"], d.get("collected", "profiles/"), ALGO_BYTES[args.workload])
+                doc = json.load(open(pmc))
+                d = doc.get(args.workload)
+                # the counters are replayed from a committed collection (tools/evidence.sh), not measured by this run: quoted only while the
+                # kernels are the ones they were collected on (sha256 over sgcount_amd/csrc/*.hip + sgc_*.h, recorded by tools/pmc_traffic.py)
+                if doc.get("kernel_sources_sha16") == kernel_sources_sha16():
+                    traffic = d["hbm_bytes_per_step"]
+                    traffic_note = "%.1f HBM B/read measured (%s) vs %.0f algorithmic" % (d["bytes_per_read"], d.get("collected", "profiles/"), ALGO_BYTES[args.workload])
+                else:
+                    traffic_note = ("not quoted: profiles/pmc_traffic.json was collected on other kernel sources (%s, now %s) — re-run tools/evidence.sh"
+                                    % (doc.get("kernel_sources_sha16"), kernel_sources_sha16()))
             except Exception:
                 traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -694,6 +886,20 @@ def main():
                 out["e2e"] = e2e_block(wl, args, exact, base)
             except Exception as e:              # the e2e leg must never cost the headline line
                 out["e2e"] = {"error": repr(e)[:500]}
+        if world == 1 and args.other_configs and args.reads >= (1 << 25):
+            try:
+                out["other_configs"] = other_configs(args, exact, L, offset, recursion, dev_index)
+            except Exception as e:
+                out["other_configs"] = {"error": repr(e)[:500]}
+        if world > 1 and args.multi_sample_reads > 0:
+            # N samples through ONE command line dealt to the N devices (the other ranks wait at the barrier below, their devices idle):
+            # the host-bound end-to-end curve next to the resident-record one
+            try:
+                cands = [args.e2e_dir] if args.e2e_dir else ["/dev/shm", "/tmp"]
+                where = max(cands, key=lambda c: _free_bytes(c) if c and os.path.isdir(c) else 0)
+                out["e2e"] = {"multi_sample": multi_sample_leg(wl, args, exact, world, where)}
+            except Exception as e:
+                out["e2e"] = {"multi_sample": {"error": repr(e)[:500]}}
         print(json.dumps(out), flush=True)
     wl.close()
     if world > 1:

@@ -217,8 +217,9 @@ void sgc_sample_free(sgc_sample *);
 void *sgc_alloc_pinned(size_t bytes);
 void sgc_free_pinned(void *p);
 
-/* Tuning knobs (all results-preserving): "variant" (count path variant 0..4; default 4), "max_chunk"
- * (records per internal pass), "k1_wgs" (workgroups of the partition kernel), "per_lane" (variant 2), "host_build" /
+/* Tuning knobs (all results-preserving): "variant" (count path variant, DESIGN.md §4: 4 = the shipped pass, default; 3 = the probing
+ * resolver, what a library without a core index gets; 1 = the generic kernels, what a library without one-word records gets), "max_chunk"
+ * (records per internal pass), "k1_wgs" (workgroups of the partition kernel), "host_build" /
  * "perm_bloom_bits" (how the next sgc_set_library builds the single-mismatch table and its filter), "force_bytes" (the next
  * sgc_set_library uses the byte-string path even for a library the packed path could serve), "place_trials" (1..64, default 1 = off:
  * where the block pool of a large pass — 32M records or more — falls in device memory decides whether its partition and

@@ -131,9 +131,8 @@ struct sgc_ctx {
     void *d_pool = nullptr; size_t pool_cap = 0;        // partitioned path: record blocks
     void *d_desc = nullptr; size_t desc_cap = 0;        // partitioned path: block descriptors
     // options
-    int variant = 4;            // count path variant: 0 direct atomics, 1/2 gid array + LDS histogram,
-                                // 3 partitioned + probing miss resolver, 4 partitioned + in-LDS core resolver
-    int per_lane = 4;           // records per lane in the v2 lookup kernel
+    int variant = 4;            // count path variant: 1 the generic kernels (gid array + LDS histogram), 3 partitioned +
+                                // probing miss resolver, 4 partitioned + in-LDS core resolver (shipped)
     uint32_t dbg = 0;           // timing-only ablation flags / phase stamps (only in -DSGC_ABLATE=1 / -DSGC_STAMPS=1 builds; results are wrong when an ablation is on)
     uint32_t k1_wgs = 512;      // workgroups of the partition kernel: two per CU (more leave more half-empty blocks open, fewer expose its phases)
     uint64_t max_chunk = 1ull << 27;   // records per internal pass (bounds the scratch buffers)
@@ -476,21 +475,14 @@ static int count_records(sgc_sample *s, const uint64_t *d_recs, uint64_t n, bool
             HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_join, 0));
             { timed t(c, T_HIST); sgc_launch_part_k4(c->stream, n_g, g, (const uint32_t *)c->d_gids,
                                                      (const uint32_t *)c->d_aux, c32, s->d_matched); }
-        } else if (c->variant == 0) {
-            timed t(c, T_LOOKUP);
-            sgc_launch_count_direct(c->stream, p, chunk, c->L, c->rec16, c->v_lib, c->v_perm, c->one_mm, c32,
-                                    s->d_matched);
         } else {
+            // the generic kernels (variant 1): any record layout, any table layout — one gid per read, then an LDS histogram
             int rc = ensure(&c->d_gids, &c->gids_cap, (size_t)chunk * 4);
             if (rc) return rc;
             {
                 timed t(c, T_LOOKUP);
-                if (c->variant >= 2 && !c->rec16 && c->v_lib.gid_bits != 0)
-                    sgc_launch_lookup_gids_v2(c->stream, p, chunk, c->L, c->v_lib, c->v_perm, c->one_mm, c->per_lane,
-                                              (uint32_t *)c->d_gids, s->d_matched);
-                else
-                    sgc_launch_lookup_gids(c->stream, p, chunk, c->L, c->rec16, c->v_lib, c->v_perm, c->one_mm,
-                                           (uint32_t *)c->d_gids, s->d_matched);
+                sgc_launch_lookup_gids(c->stream, p, chunk, c->L, c->rec16, c->v_lib, c->v_perm, c->one_mm,
+                                       (uint32_t *)c->d_gids, s->d_matched);
             }
             {
                 timed t(c, T_HIST);
@@ -674,7 +666,7 @@ int sgc_ctx_clone(sgc_ctx *src, sgc_ctx **out) {
     c->hybrid = src->hybrid; c->n_packed = src->n_packed; c->d_gid_map = src->d_gid_map; c->d_bloom_shadow = src->d_bloom_shadow; c->b_shadow = src->b_shadow;
     c->bytes_mode = src->bytes_mode; c->d_bytes_seqs = src->d_bytes_seqs; c->d_bytes_pl = src->d_bytes_pl; c->v_bytes = src->v_bytes;
     // and the options that shape the passes
-    c->variant = src->variant; c->per_lane = src->per_lane; c->k1_wgs = src->k1_wgs; c->max_chunk = src->max_chunk;
+    c->variant = src->variant; c->k1_wgs = src->k1_wgs; c->max_chunk = src->max_chunk;
     c->batch_records = src->batch_records; c->dense = src->dense; c->direct = src->direct; c->six_byte = src->six_byte;
     c->five_byte = src->five_byte; c->wide = src->wide; c->balanced = src->balanced; c->tag_sub = src->tag_sub; c->use_cuckoo = src->use_cuckoo; c->place_trials = src->place_trials;
     c->verbose = src->verbose; c->host_routes = src->host_routes;
@@ -702,7 +694,13 @@ void sgc_free_pinned(void *p) { if (p) hipHostFree(p); }
 
 int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
     if (!c || !key) return fail(SGC_E_ARG, "sgc_set_option: NULL argument");
-    if (!strcmp(key, "variant")) { c->variant = (int)value; return SGC_OK; }
+    if (!strcmp(key, "variant")) {
+        // 4: the shipped pass; 3: the probing resolver (what a library without a core index gets); 1: the generic kernels (what a
+        // library without one-word records or packed slots gets).  Rounds 1-3 also kept 0 (direct atomics) and 2 (a lookup kernel
+        // that variant 3 superseded): they served no library shape any more and are gone.
+        if (value != 1 && value != 3 && value != 4) return fail(SGC_E_ARG, "sgc_set_option: variant must be 1, 3 or 4");
+        c->variant = (int)value; return SGC_OK;
+    }
     if (!strcmp(key, "dbg")) {
         // timing-only ablation flags / phase stamps of the kernels: they exist only in a library built for it (sgc_kernels.h)
         if (value && !(SGC_ABLATE || SGC_STAMPS_BUILD))
@@ -766,10 +764,6 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
         sgc_core_print_occupancy();
         fprintf(stderr, "scratch: pool %p (%zu MB) runs %p (%zu MB) desc %p\n", c->d_pool, c->pool_cap >> 20, c->d_cbuf, c->cbuf_cap >> 20, c->d_desc);
         return SGC_OK;
-    }
-    if (!strcmp(key, "per_lane")) {
-        if (value != 1 && value != 2 && value != 4) return fail(SGC_E_ARG, "per_lane must be 1, 2 or 4");
-        c->per_lane = (int)value; return SGC_OK;
     }
     return fail(SGC_E_ARG, std::string("sgc_set_option: unknown key ") + key);
 }

@@ -33,9 +33,6 @@ struct sgc_bloom_view {
     uint32_t pad_;
 };
 
-void sgc_launch_count_direct(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, bool rec16,
-                             const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm, uint32_t *counts,
-                             unsigned long long *matched);
 void sgc_launch_lookup(hipStream_t st, const uint64_t *keys, uint64_t n, const sgc_table_view &lib,
                        const sgc_table_view &perm, int which, bool has_perm, int32_t *out);
 void sgc_launch_fold(hipStream_t st, uint32_t *c32, unsigned long long *c64, uint32_t n);
@@ -47,9 +44,6 @@ void sgc_launch_lookup_gids(hipStream_t st, const uint64_t *recs, uint64_t n, ui
                             const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm, uint32_t *gids,
                             unsigned long long *matched);
 void sgc_launch_hist_slices(hipStream_t st, const uint32_t *gids, uint64_t n, uint32_t n_guides, uint32_t *counts);
-void sgc_launch_lookup_gids_v2(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L,
-                               const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm, int per_lane,
-                               uint32_t *gids, unsigned long long *matched);
 
 // ---- partitioned count path (sgc_part.hip) ------------------------------------------------------
 #define SGC_DESC_TAIL 69632u

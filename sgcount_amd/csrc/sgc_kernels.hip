@@ -14,27 +14,6 @@
 #include "sgc_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
-// v0 count kernel: one record per thread (grid-stride), device-scope atomics on the count vector.
-// Kept as the simple reference variant (SGC_VARIANT=0); the tuned path is below.
-// ------------------------------------------------------------------------------------------------
-template <bool PACKED, bool REC16>
-__global__ void __launch_bounds__(256) k_count_direct(const uint64_t *__restrict__ recs, uint64_t n, uint32_t L,
-                                                      sgc_table_view lib, sgc_table_view perm, int one_mm,
-                                                      uint32_t *__restrict__ counts,
-                                                      unsigned long long *__restrict__ matched) {
-    uint64_t local = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t span, status;
-        load_record<REC16>(recs, i, L, span, status);
-        const uint32_t g = sgc_assign<PACKED>(span, status, L, lib, perm, one_mm != 0);
-        if (g != SGC_NONE) { atomicAdd(&counts[g], 1u); local++; }
-    }
-    // wave reduction of the matched tally, one atomic per wave
-    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(matched, (unsigned long long)local);
-}
-
-// ------------------------------------------------------------------------------------------------
 // variant 1: lookup kernel writes one gid per read (coalesced u32 stores, no count atomics); a second
 // kernel builds the histogram in LDS, one guide-range slice per pass, and flushes each slice with
 // contiguous (256 B per wave-instruction) device-scope atomics.  Scattered device-scope atomics run at
@@ -52,79 +31,6 @@ __global__ void __launch_bounds__(256) k_lookup_gids(const uint64_t *__restrict_
         const uint32_t g = sgc_assign<PACKED>(span, status, L, lib, perm, one_mm != 0);
         gids[i] = g;
         local += g != SGC_NONE;
-    }
-    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(matched, (unsigned long long)local);
-}
-
-// ------------------------------------------------------------------------------------------------
-// variant 2 lookup: R records per lane and speculative probing.
-//   phase A  every lane probes the library with the Centered key of its R records (R independent
-//            gathers in flight per lane instead of one);
-//   phase B  a record that missed issues both remaining library probes (Plus, Minus: cheap, L2) at once
-//            and walks the permute probes (Infinity Cache: ~5x dearer per gather) only as far as the
-//            reference's priority order needs them (src/counter.rs:111-135).
-//   Records with a non-zero status (an 'N', a dead window, a short read: ~2 % of reads) take the
-//   generic sequential path.  rec8 + packed tables only; other layouts use k_lookup_gids.
-// Streaming traffic (records in, gids out) is non-temporal so that it does not evict the 2 MB library
-// table from the XCD's L2.
-// ------------------------------------------------------------------------------------------------
-template <bool ONE_MM, int R>
-__global__ void __launch_bounds__(256) k_lookup_gids_v2(const uint64_t *__restrict__ recs, uint64_t n, uint32_t L,
-                                                        sgc_table_view lib, sgc_table_view perm,
-                                                        uint32_t *__restrict__ gids,
-                                                        unsigned long long *__restrict__ matched) {
-    const uint32_t sh = 2 * (L + 2);
-    const uint64_t smask = (1ull << sh) - 1ull, kmask = sgc_key_mask(L);
-    uint64_t local = 0;
-    const uint64_t n_groups = n / R;
-    for (uint64_t grp = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; grp < n_groups;
-         grp += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t rec[R], keyC[R];
-        ulonglong2 sl[R];
-        uint32_t hC[R], g[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) rec[r] = __builtin_nontemporal_load(&recs[grp * R + r]);
-        // phase A
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            keyC[r] = (rec[r] >> 2) & kmask;
-            hC[r] = bucket_of(lib, keyC[r]);
-            sl[r] = load_bucket(lib, hC[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            if ((rec[r] >> sh) != 0) g[r] = sgc_assign<true>(rec[r] & smask, rec[r] >> sh, L, lib, perm, ONE_MM);
-            else g[r] = finish_find(lib, keyC[r], hC[r], sl[r]);
-        }
-        // phase B
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            if (g[r] != SGC_NONE || (rec[r] >> sh) != 0) continue;
-            const uint64_t keyP = (rec[r] >> 4) & kmask, keyM = rec[r] & kmask;
-            const uint32_t hP = bucket_of(lib, keyP), hM = bucket_of(lib, keyM);
-            const ulonglong2 a1 = load_bucket(lib, hP), a3 = load_bucket(lib, hM);
-            uint32_t x = SGC_NONE;
-            if (ONE_MM) x = table_find<true>(perm, keyC[r]);
-            if (x == SGC_NONE) x = finish_find(lib, keyP, hP, a1);
-            if (ONE_MM && x == SGC_NONE) x = table_find<true>(perm, keyP);
-            if (x == SGC_NONE) x = finish_find(lib, keyM, hM, a3);
-            if (ONE_MM && x == SGC_NONE) x = table_find<true>(perm, keyM);
-            g[r] = x;
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            __builtin_nontemporal_store(g[r], &gids[grp * R + r]);
-            local += g[r] != SGC_NONE;
-        }
-    }
-    // tail (n % R records), one lane each
-    const uint64_t tail0 = n_groups * R, t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n - tail0) {
-        const uint64_t rec = recs[tail0 + t];
-        const uint32_t x = sgc_assign<true>(rec & smask, rec >> sh, L, lib, perm, ONE_MM);
-        gids[tail0 + t] = x;
-        local += x != SGC_NONE;
     }
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(matched, (unsigned long long)local);
@@ -211,19 +117,6 @@ static inline unsigned grid_for(uint64_t n, unsigned block, unsigned cap) {
     return (unsigned)g;
 }
 
-void sgc_launch_count_direct(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, bool rec16,
-                             const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm, uint32_t *counts,
-                             unsigned long long *matched) {
-    if (n == 0) return;
-    const unsigned block = 256, grid = grid_for(n, block, 256 * 8 * 4);
-    const bool packed = lib.gid_bits != 0;
-#define SGC_GO(P, R) \
-    hipLaunchKernelGGL((k_count_direct<P, R>), dim3(grid), dim3(block), 0, st, recs, n, L, lib, perm, (int)one_mm, counts, matched)
-    if (packed) { if (rec16) SGC_GO(true, true); else SGC_GO(true, false); }
-    else        { if (rec16) SGC_GO(false, true); else SGC_GO(false, false); }
-#undef SGC_GO
-}
-
 void sgc_launch_lookup_gids(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L, bool rec16,
                             const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm, uint32_t *gids,
                             unsigned long long *matched) {
@@ -234,20 +127,6 @@ void sgc_launch_lookup_gids(hipStream_t st, const uint64_t *recs, uint64_t n, ui
     hipLaunchKernelGGL((k_lookup_gids<P, R>), dim3(grid), dim3(block), 0, st, recs, n, L, lib, perm, (int)one_mm, gids, matched)
     if (packed) { if (rec16) SGC_GO(true, true); else SGC_GO(true, false); }
     else        { if (rec16) SGC_GO(false, true); else SGC_GO(false, false); }
-#undef SGC_GO
-}
-
-void sgc_launch_lookup_gids_v2(hipStream_t st, const uint64_t *recs, uint64_t n, uint32_t L,
-                               const sgc_table_view &lib, const sgc_table_view &perm, bool one_mm, int per_lane,
-                               uint32_t *gids, unsigned long long *matched) {
-    if (n == 0) return;
-    const unsigned block = 256;
-    const uint64_t groups = (n + per_lane - 1) / per_lane;
-    const unsigned grid = grid_for(groups, block, 256 * 8 * 2);
-#define SGC_GO(M, R) \
-    hipLaunchKernelGGL((k_lookup_gids_v2<M, R>), dim3(grid), dim3(block), 0, st, recs, n, L, lib, perm, gids, matched)
-    if (one_mm) { if (per_lane == 4) SGC_GO(true, 4); else if (per_lane == 2) SGC_GO(true, 2); else SGC_GO(true, 1); }
-    else        { if (per_lane == 4) SGC_GO(false, 4); else if (per_lane == 2) SGC_GO(false, 2); else SGC_GO(false, 1); }
 #undef SGC_GO
 }
 

@@ -54,9 +54,13 @@ def main():
         out[w] = {"hbm_bytes_per_step": tot, "bytes_per_read": tot / n_reads, "fetch_correction": cal,
                   "collected": "profiles/%s" % (sys.argv[5] if len(sys.argv) > 5 else "?"),
                   "unit": "bytes per 100M-read pass (FETCH_SIZE x correction + WRITE_SIZE)", "kernels": kern}
+    # which kernels these bytes belong to: bench.py quotes roofline.traffic only while the device sources are these
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_sources_sha16
+    out["kernel_sources_sha16"] = kernel_sources_sha16()
     json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles",
                                      "pmc_traffic.json"), "w"), indent=1)
-    for w in out:
+    for w in ("1mm", "exact"):
         print(w, "%.2f GB per pass, %.1f B/read, fetch correction x%.2f" % (out[w]["hbm_bytes_per_step"] / 1e9,
                                                                              out[w]["bytes_per_read"], out[w]["fetch_correction"]))
         for k, v in out[w]["kernels"].items():

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of count-kernel variants in ONE process (interleaved rounds), on the bench workload.
 
-    python tools/tune.py --reads 100000000 --variants 0,1 --rounds 3 --workload 1mm
+    python tools/tune.py --reads 100000000 --variants 4,3 --rounds 3 --workload 1mm
 Prints per variant: median/min of Σ kernel time per pass (lookup, hist), and checks every variant
 returns the same count table.
 """
@@ -25,7 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reads", type=int, default=100_000_000)
     ap.add_argument("--guides", type=int, default=100_000)
-    ap.add_argument("--variants", default="0,1")
+    ap.add_argument("--variants", default="4")
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--workload", choices=["1mm", "exact"], default="1mm")
