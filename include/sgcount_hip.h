@@ -75,11 +75,15 @@ typedef struct {
                                   mode, where one exact-only pass uses it); 0 = no core index (L outside 4..23, split-layout
                                   table, or the guides do not spread): probing resolver */
     uint32_t path;             /* which count path serves this library with the default options — the fallbacks are results-preserving but
-                                  not equally fast: 4 = partitioned pass + in-LDS core resolver (the shipped path: L <= 23,
-                                  <= 128 slices = ~210k guides); 3 = partitioned pass + probing resolver (no core index); 1 = guide-id
-                                  array + LDS histogram (two-word records, split-layout tables, more than 128 slices); 0 = byte-string
-                                  path (record_bytes == 0) */
-    uint32_t slices;           /* library slices of the partitioned pass (0 if path < 3); 64 at 100k guides; 128 costs ~35 % */
+                                  not equally fast (rates on the 100M-read bench sample, MI355X): 4 = partitioned pass +
+                                  in-LDS core resolver (the shipped path: L <= 23; 100k guides 117-128 G reads/s, 150k-200k guides — 128
+                                  slices — ~70 G, 250k-300k guides — 128 slices of 2^13 slots — 90-95 G); 3 = partitioned pass + probing
+                                  resolver (no core index: L = 24..30 never, guides that share a 9-base stretch by the thousand, or more
+                                  than ~340k guides; 400k guides 47 G); 1 = guide-id array + LDS histogram (two-word records, split-layout
+                                  tables, more than 128 slices of 2^13 slots = ~420k guides: 20-26 G); 0 = byte-string path
+                                  (record_bytes == 0) */
+    uint32_t slices;           /* library slices of the partitioned pass (0 if path < 3): 64 at 100k guides; up to 128 of 2^12 table
+                                  slots (~210k guides), beyond that up to 128 of 2^13 slots (one slice-count workgroup per CU) */
     uint32_t slice_record_bytes; /* bytes of a clean record inside a slice block: 5, 6 or 8 (0 if path < 3) */
     uint32_t reserved_;
 } sgc_lib_info;

@@ -869,7 +869,7 @@ static int set_library_packed(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint3
         lap_t = now;
     };
     const uint32_t want_cl = (c->align_slices && L >= 4 && L <= SGC_REC8_MAXL) ? (L - 2) / 2 : 0;
-    int rc = sgc_build_library_table(seqs, n, L, SGC_LDS_LOG2_SLICE, want_cl, keys, h_lib, err);
+    int rc = sgc_build_library_table(seqs, n, L, sgc_choose_log2_slice(n), want_cl, keys, h_lib, err);
     if (rc != SGC_OK) return fail(rc, "sgc_set_library: " + err);
     lap("library table (host)");
     rc = upload_table(h_lib, &c->d_lib_slots, &c->d_lib_vals, &c->v_lib, c->stream);
@@ -1532,7 +1532,7 @@ int sgc_check_host_tables(const uint8_t *seqs, uint32_t n, uint32_t L, int enabl
     std::vector<uint64_t> keys;
     sgc_host_table h;
     const uint32_t want_cl = (L >= 4 && L <= SGC_REC8_MAXL) ? (L - 2) / 2 : 0;
-    int rc = sgc_build_library_table(seqs, n, L, SGC_LDS_LOG2_SLICE, want_cl, keys, h, err);
+    int rc = sgc_build_library_table(seqs, n, L, sgc_choose_log2_slice(n), want_cl, keys, h, err);
     if (rc == SGC_E_UNSUPPORTED && L >= 1 && n >= 1) {
         // byte-string tables (sgc_bytes.h): probe the library table for every guide, the children table for every stored child
         sgc_host_bytes hb;
@@ -1570,7 +1570,7 @@ int sgc_check_host_tables(const uint8_t *seqs, uint32_t n, uint32_t L, int enabl
     }
     // the two-choice image of the slices (k_count_slices): home slot or its alternate, nowhere else
     std::vector<uint64_t> ck;
-    if (h.gid_bits && h.log2_slice <= SGC_LDS_LOG2_SLICE && sgc_build_slice_cuckoo(h, ck)) {
+    if (h.gid_bits && h.log2_slice <= SGC_LDS_LOG2_SLICE_BIG && sgc_build_slice_cuckoo(h, ck)) {
         stats[3] = 1;
         for (uint32_t g = 0; g < n; g++) {
             const uint32_t hs = sgc_home_slot_ex(keys[g], h.log2_slots, h.log2_slice, h.core_cl);

@@ -24,6 +24,18 @@
 // slots per library-table slice staged in LDS by the partitioned path: 2^12 x 8 B = 32 KiB of keys plus
 // 16 KiB of counters, so that two 1024-lane workgroups share a CU's 160 KiB
 #define SGC_LDS_LOG2_SLICE 12u
+// ... and for a library that would need more than 128 such slices (> ~210k guides: tiling and paired-guide libraries): slices of 2^13
+// slots — 64 KiB of keys + 32 KiB of counters, ONE workgroup of k_count_slices per CU (it runs at 0.94 of the rate of two:
+// tools/occupancy_probe.sh) — so that the partitioned pass serves up to ~420k guides (round 4; before, such a library fell to the generic kernels)
+#define SGC_LDS_LOG2_SLICE_BIG 13u
+#define SGC_PART_MAX_LOG2_SLICES 7u      // k_partition deals records to at most 128 slices (+ the generic partition)
+// the slice size for a library of n guides (table load <= 0.4, as sgc_build_library_table allocates it)
+static inline uint32_t sgc_choose_log2_slice(uint64_t n_guides) {
+    uint64_t want = (uint64_t)((double)n_guides / 0.4) + 1;
+    uint32_t l = 4;
+    while ((1ull << l) < want) l++;
+    return l > SGC_LDS_LOG2_SLICE + SGC_PART_MAX_LOG2_SLICES ? SGC_LDS_LOG2_SLICE_BIG : SGC_LDS_LOG2_SLICE;
+}
 // 64-bit words of the library Bloom filter the miss resolver stages in LDS (2^13 x 8 B = 64 KiB)
 #define SGC_LIB_BLOOM_LOG2_WORDS 13u
 

@@ -618,7 +618,9 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 const uint64_t key = (cur[q] >> 2) & kmask;
                 // home slot inside the slice: left there by k_partition, or (six-byte records) hashed again here
                 const uint32_t h32 = sgc_hash32(key);
-                const uint32_t s1 = P6 ? h32 >> (32u - ls) : (uint32_t)(cur[q] >> PART_TAG_SHIFT);
+                // (k_partition's slot tag has twelve bits: with slices of 2^13 slots the slot is computed here, whatever the record format)
+                const uint32_t s1 = P6 ? h32 >> (32u - ls) :
+                                    LOG2_SLICE > 12 ? (sgc_home_slot_ex(key, lib.log2_slots, lib.log2_slice, lib.core_cl) & (slice - 1u)) : (uint32_t)(cur[q] >> PART_TAG_SHIFT);
                 uint32_t b = s1 >> 1, slot;
                 ulonglong2 wv;
                 bool hit;
@@ -1039,8 +1041,8 @@ __global__ void __launch_bounds__(1024) k_hist_segments(const uint32_t *__restri
 // ------------------------------------------------------------------------------------------------ host side
 bool sgc_part_supported(const sgc_table_view &lib, bool rec16) {
     if (rec16 || lib.gid_bits == 0) return false;
-    if (lib.log2_slice > SGC_LDS_LOG2_SLICE || lib.log2_slice < 1) return false;
-    return (lib.log2_slots - lib.log2_slice) <= 7;      // <= PART_MAXP partitions
+    if (lib.log2_slice > SGC_LDS_LOG2_SLICE_BIG || lib.log2_slice < 1) return false;
+    return (lib.log2_slots - lib.log2_slice) <= SGC_PART_MAX_LOG2_SLICES;      // <= PART_MAXP partitions
 }
 
 void sgc_part_plan(uint64_t n, const sgc_table_view &lib, uint32_t max_wgs, sgc_part_geometry *g) {
@@ -1102,9 +1104,14 @@ void sgc_launch_part_k2(hipStream_t st, uint32_t L, const sgc_table_view &lib, c
     const uint32_t *wcnt = (const uint32_t *)((const char *)desc + g.wcnt_off), *wlist = (const uint32_t *)((const char *)desc + g.wlist_off);
     const bool dense = runs && mrun;
     const bool direct = dense && direct_runs && runs->sub_bits != 0xFFu;
+    // (slices of 2^13 slots — libraries beyond 128 slices of 2^12 — take the same kernel with twice the LDS: one workgroup per CU)
 #define K2_LAUNCH(CK, DN, DR, REC)                                                                                                     \
-    hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE, CK, DN, DR, REC>), dim3(grid), dim3(K2_THREADS), sgc_extra_lds("K2"), st, pool, desc, wcnt, wlist, \
-                       g.k1_wgs, g.blocks_per_wg, G, L, lib, counts, matched, dbg, runs ? *runs : none, cuckoo, mrun, mcur, slice_tot, slice_tot_next)
+    do { if (lib.log2_slice > SGC_LDS_LOG2_SLICE)                                                                                      \
+        hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE_BIG, CK, DN, DR, REC>), dim3(grid), dim3(K2_THREADS), sgc_extra_lds("K2"), st, pool, desc, wcnt, wlist, \
+                           g.k1_wgs, g.blocks_per_wg, G, L, lib, counts, matched, dbg, runs ? *runs : none, cuckoo, mrun, mcur, slice_tot, slice_tot_next); \
+    else                                                                                                                               \
+        hipLaunchKernelGGL((k_count_slices<SGC_LDS_LOG2_SLICE, CK, DN, DR, REC>), dim3(grid), dim3(K2_THREADS), sgc_extra_lds("K2"), st, pool, desc, wcnt, wlist, \
+                           g.k1_wgs, g.blocks_per_wg, G, L, lib, counts, matched, dbg, runs ? *runs : none, cuckoo, mrun, mcur, slice_tot, slice_tot_next); } while (0)
     const int rec = direct ? slice_rec : 0;          // 0 = 8-byte, 1 = six-byte, 2 = five-byte slice blocks
     const bool l20 = L == 20 && rec == 2 && cuckoo && lib.core_cl == 9 && lib.log2_slice == SGC_LDS_LOG2_SLICE &&
                      lib.log2_slots == SGC_LDS_LOG2_SLICE + 6u && runs->sub_bits == 2;

@@ -166,6 +166,40 @@ def test_large_library_128_slices(env, variant, ng):
     wl.close()
 
 
+@pytest.mark.parametrize("ng", [250_000, 400_000])
+def test_large_library_big_slices(env, ng):
+    """Libraries beyond 128 slices of 2^12 slots (> ~210k guides: tiling / paired-guide libraries) get slices of 2^13 slots — one
+    workgroup of k_count_slices per CU — and stay on the partitioned pass (round 3: the generic kernels).  250k guides: 128 big slices
+    + the in-LDS core resolver (512 core partitions); 400k guides: the core index no longer fits 512 partitions of 2048 entries, so the
+    probing resolver (path 3) takes the leftovers.  The oracle's table either way, for the default and for the fallback rungs."""
+    torch, S, synth, workload = env
+    n = 1_500_000
+    wl = workload.DeviceWorkload(n, ng, 20, one_mismatch=True, gen_chunk=700_000)
+    info = wl.dl.info()
+    assert info.lib_slots == 1 << 20 and info.slices == 128
+    assert info.path == (4 if ng == 250_000 else 3), info.path
+    lib_text = synth.library_fasta(wl.lib_seqs)
+    lib = O.Library(lib_text)
+    ctr = O.Counter(lib, O.Permuter(lib), False, 30, 20, True)
+    for first in range(0, n, 500_000):
+        ctr.feed_text(synth.fastq_host(wl.lib_seqs, first, 500_000))
+    want = (ctr.table(), ctr.total_reads(), ctr.matched_reads())
+    for opts in ({}, {"cuckoo": 0}, {"five_byte": 0}, {"variant": 3}, {"variant": 1}):
+        for k, v in opts.items():
+            wl.dl.set_option(k, v)
+        wl.step()
+        counts, total, matched = wl.result()
+        assert (counts.tolist(), total, matched) == want, opts
+        for k in opts:
+            wl.dl.set_option(k, 4 if k == "variant" else 1)
+    wl.dl.timing(True); wl.dl.timing(reset=True)
+    wl.step()
+    torch.cuda.synchronize()
+    assert wl.dl.timing(reset=True).part_ms > 0            # the partitioned kernels ran
+    wl.dl.timing(False)
+    wl.close()
+
+
 @pytest.mark.parametrize("L,reverse,recursion", [(20, False, True), (20, True, False), (27, False, True)])
 def test_fastq_ingest_on_device(env, L, reverse, recursion):
     """sgc_sample_push_fastq: record boundaries + packing on the GPU from raw FASTQ text == the oracle fed the
