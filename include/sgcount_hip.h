@@ -77,7 +77,7 @@ typedef struct {
     uint32_t path;             /* which count path serves this library with the default options — the fallbacks are results-preserving but
                                   not equally fast (rates on the 100M-read bench sample, MI355X): 4 = partitioned pass +
                                   in-LDS core resolver (the shipped path: L <= 23; 100k guides 117-128 G reads/s, 150k-200k guides — 128
-                                  slices — ~70 G, 250k-300k guides — 128 slices of 2^13 slots — 90-95 G); 3 = partitioned pass + probing
+                                  slices — 100-109 G, 250k-300k guides — 128 slices of 2^13 slots — 90-95 G); 3 = partitioned pass + probing
                                   resolver (no core index: L = 24..30 never, guides that share a 9-base stretch by the thousand, or more
                                   than ~340k guides; 400k guides 47 G); 1 = guide-id array + LDS histogram (two-word records, split-layout
                                   tables, more than 128 slices of 2^13 slots = ~420k guides: 20-26 G); 0 = byte-string path

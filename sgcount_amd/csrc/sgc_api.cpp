@@ -139,6 +139,7 @@ struct sgc_ctx {
     uint64_t batch_records = 1ull << 24;   // sgc_sample_push_packed_async: records per device-side batch (one count pass each)
     bool rest_filter = true;           // core pass A settles "no parent inside the core" with the rest filter (sgc_format.h)
     bool align_slices = true;          // build the library table with slices that follow the core hash (next sgc_set_library)
+    int slice_log2 = 0;                // 0: sgc_choose_log2_slice(n); 12 / 13: slots per library slice of the next sgc_set_library (tuning)
     bool host_build = false;           // build the single-mismatch table on the host (sgc_tables.cpp) instead of the GPU
     uint32_t perm_bloom_bits = 8;      // Bloom bits per child of the single-mismatch filter
     // timing
@@ -724,6 +725,10 @@ int sgc_set_option(sgc_ctx *c, const char *key, int64_t value) {
         c->batch_records = (uint64_t)value; return SGC_OK;          // takes effect for samples that have not pushed asynchronously yet
     }
     if (!strcmp(key, "align_slices")) { c->align_slices = value != 0; return SGC_OK; }       // takes effect at the next sgc_set_library
+    if (!strcmp(key, "slice_log2")) {
+        if (value != 0 && value != SGC_LDS_LOG2_SLICE && value != SGC_LDS_LOG2_SLICE_BIG) return fail(SGC_E_ARG, "sgc_set_option: slice_log2 must be 0, 12 or 13");
+        c->slice_log2 = (int)value; return SGC_OK;
+    }
     if (!strcmp(key, "force_bytes")) { c->force_bytes = value != 0; return SGC_OK; }         // takes effect at the next sgc_set_library
     if (!strcmp(key, "host_routes")) { c->host_routes = value != 0; return SGC_OK; }
     if (!strcmp(key, "hybrid")) { c->allow_hybrid = value != 0; return SGC_OK; }             // 0: a library with any byte outside ACGT is served by the byte-string path alone (next sgc_set_library)
@@ -869,7 +874,7 @@ static int set_library_packed(sgc_ctx *c, const uint8_t *seqs, uint32_t n, uint3
         lap_t = now;
     };
     const uint32_t want_cl = (c->align_slices && L >= 4 && L <= SGC_REC8_MAXL) ? (L - 2) / 2 : 0;
-    int rc = sgc_build_library_table(seqs, n, L, sgc_choose_log2_slice(n), want_cl, keys, h_lib, err);
+    int rc = sgc_build_library_table(seqs, n, L, c->slice_log2 ? (uint32_t)c->slice_log2 : sgc_choose_log2_slice(n), want_cl, keys, h_lib, err);
     if (rc != SGC_OK) return fail(rc, "sgc_set_library: " + err);
     lap("library table (host)");
     rc = upload_table(h_lib, &c->d_lib_slots, &c->d_lib_vals, &c->v_lib, c->stream);
