@@ -166,6 +166,7 @@ class TextFeeder {
     void release_below(size_t k);       // the buffers of slices < k may be refilled
     uint8_t first_byte = 0;             // first byte of the text
     bool is_gz = false, is_bgzf = false, is_pgz = false;      // is_pgz: one gzip stream inflated by several threads
+    bool plain_mapped = false;           // plain text: the readers copy from a mapping of the file (no first-read LRU activation)
     size_t file_size = 0, n_threads = 1;
     size_t pgz_chunk_bytes = 0;          // compressed bytes per unit of speculative work (0 = chosen from the file size)
     size_t pgz_fallbacks = 0;            // chunks whose speculative start was wrong or missing and that were decoded in order instead
