@@ -138,6 +138,19 @@ void sgc_part_timeline_dump() {
 #endif
 }
 
+// inclusive prefix sum over the 64 lanes of a wave with data-parallel primitives (row shifts inside the rows of 16 lanes, then the two
+// row broadcasts of gfx9): six dependent vector instructions — the same scan written with __shfl_up goes through the LDS crossbar six
+// times, 0.9 us per tile of k_partition with fifteen waves waiting for it (the phase stamps of round 4)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);      // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);      // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);      // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);      // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);      // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------ K1
 template <int MODE>
 __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__restrict__ recs, uint64_t n, uint64_t per_wg,
@@ -151,7 +164,10 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
     SGC_TIMELINE_BEGIN(dbg);
     __shared__ uint64_t stage[PART_TILE];
     __shared__ uint8_t stage_p[PART_TILE];               // partition of every staged record
-    __shared__ uint32_t cnt[PART_ARR], start[PART_ARR], blk[PART_ARR], fill[PART_ARR];
+    // (the tile counts in two copies, used in turn: a tile's counts are zeroed while the tile before is staged, so that a tile needs three
+    // barriers — ranked | scanned | staged — and neither one in front of its ranking nor one behind its writes: whoever enters the next
+    // tile's scan or staging has passed that tile's first barrier, which every wave reaches only behind its own writes of this one)
+    __shared__ uint32_t cnt2[2][PART_ARR], start[PART_ARR], blk[PART_ARR], fill[PART_ARR];
     __shared__ uint32_t nblk[PART_ARR];
     // where a partition's run of the current tile goes, in one 16-byte word per partition (one LDS read per record in the
     // write loop): x = first record of the run inside the staged tile, y = records that top up the open block, z = pool
@@ -164,15 +180,18 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
     const uint64_t lo = (uint64_t)blockIdx.x * per_wg;
     const uint64_t hi = lo + per_wg < n ? lo + per_wg : n;
     const uint32_t block0 = blockIdx.x * blocks_per_wg;
-    if (t < PART_ARR) { blk[t] = 0xFFFFFFFFu; fill[t] = PART_BLOCK; nblk[t] = 0; }
+    if (t < PART_ARR) { blk[t] = 0xFFFFFFFFu; fill[t] = PART_BLOCK; nblk[t] = 0; cnt2[0][t] = 0; cnt2[1][t] = 0; }
     if (t == 0) next_free = 0;
     __syncthreads();
+    uint32_t tile_par = 0;
+    // (-DSGC_STAMPS=1, dbg 1048576: thread 0's time in the phases of the tiles — loaded and ranked | scanned | staged | written; each ends at its barrier)
+    unsigned long long k1_ph[4] = {0, 0, 0, 0}, k1_x = SGC_STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
+#define K1_PHASE(i) if (SGC_STAMPS && (dbg & 1048576u)) { const unsigned long long y_ = __builtin_amdgcn_s_memtime(); k1_ph[i] += y_ - k1_x; k1_x = y_; }
     // two workgroups per CU (64 VGPRs each: __launch_bounds__(1024, 8)) — while one waits for its tile's records the other
     // ranks, stages or writes; a register prefetch of the next tile instead (one workgroup per CU, 80 VGPRs) measured slower
     for (uint64_t base = lo; base < hi; base += PART_TILE) {
         const uint32_t m = (uint32_t)(hi - base < PART_TILE ? hi - base : PART_TILE);
-        if (t < PART_ARR) cnt[t] = 0;
-        __syncthreads();
+        uint32_t *const cnt = cnt2[tile_par];
         uint64_t rec[PART_TILE / K1_THREADS];
         uint32_t pr[PART_TILE / K1_THREADS];     // partition << 16 | rank inside the tile
 #pragma unroll
@@ -191,6 +210,7 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
             }
         }
         __syncthreads();
+        K1_PHASE(0)
         // one lane per partition: exclusive scan of the tile counts, and where the tile's run goes.  A run
         // first tops up the partition's open block, the remainder opens a new one, so every closed block is
         // full and a workgroup never needs more than per_wg / BLOCK + P blocks.
@@ -202,12 +222,8 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
             const uint32_t c = (t < P || t == PART_MAXP) ? cnt[q] : 0;
             uint32_t st0;
             if (t < PART_MAXP) {
-                uint32_t incl = c, base = 0;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const uint32_t v = __shfl_up(incl, off, 64);
-                    if ((int)lane >= off) incl += v;
-                }
+                uint32_t base = 0;
+                const uint32_t incl = wave_inclusive_scan(c);
                 if (t >= 64) {                           // wave 1: total of slices 0..63
                     base = cnt[lane];
 #pragma unroll
@@ -247,6 +263,7 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
             }
         }
         __syncthreads();
+        K1_PHASE(1)
 #pragma unroll
         for (uint32_t k = 0; k < PART_TILE / K1_THREADS; k++) {
             const uint32_t j = k * K1_THREADS + t;
@@ -256,7 +273,10 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
                 stage_p[at] = (uint8_t)(pr[k] >> 16);
             }
         }
+        if (t < PART_ARR) cnt2[tile_par ^ 1u][t] = 0;        // the next tile's counts (last read by the scan of the tile before this one)
+        tile_par ^= 1u;
         __syncthreads();
+        K1_PHASE(2)
         for (uint32_t j = t; j < m; j += K1_THREADS) {
             const uint64_t r = stage[j];
             const uint32_t p = stage_p[j];
@@ -266,15 +286,18 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
             if (!SGC_BOUND((at >> PART_LOG2_BLOCK) < gridDim.x * blocks_per_wg, err, 8)) continue;
             if ((p6 || p5) && p != P) {
                 const uint32_t bo = (at >> PART_LOG2_BLOCK) * (PART_STRIDE * 8u), idx = (at + part_rot(at >> PART_LOG2_BLOCK)) & (PART_BLOCK - 1u);
-                *reinterpret_cast<uint32_t *>(pb + (size_t)(bo + (idx << 2))) = (uint32_t)r;
-                if (p5) *reinterpret_cast<uint8_t *>(pb + (size_t)(bo + P6_HI_OFF + idx)) = (uint8_t)(r >> 32);
+                // (timing-only ablations, -DSGC_ABLATE=1: dbg 64 no high-byte store, dbg 128 no low-word store — what a second write stream per run costs)
+                if (!SGC_DBG(dbg, 128u)) *reinterpret_cast<uint32_t *>(pb + (size_t)(bo + (idx << 2))) = (uint32_t)r;
+                if (p5 && !SGC_DBG(dbg, 64u)) *reinterpret_cast<uint8_t *>(pb + (size_t)(bo + P6_HI_OFF + idx)) = (uint8_t)(r >> 32);
                 else *reinterpret_cast<uint16_t *>(pb + (size_t)(bo + P6_HI_OFF + (idx << 1))) = (uint16_t)(r >> 32);
             } else {
                 *reinterpret_cast<uint64_t *>(pb + (size_t)(((at >> PART_LOG2_BLOCK) * PART_STRIDE + (at & (PART_BLOCK - 1u))) << 3)) = r;
             }
         }
-        __syncthreads();
+        K1_PHASE(3)
     }
+#undef K1_PHASE
+    __syncthreads();
     if (t <= P && blk[t] != 0xFFFFFFFFu) {
         desc[blk[t]] = ((t + 1) << 16) | fill[t];
         wlist[((size_t)blockIdx.x * PART_ARR + t) * blocks_per_wg + nblk[t] - 1u] = (blk[t] << 11) | fill[t];
@@ -288,7 +311,7 @@ __global__ void __launch_bounds__(K1_THREADS, 8) k_partition(const uint64_t *__r
     if (slice_tot && t < P && nblk[t]) atomicAdd(&slice_tot[t], nblk[t]);
     if (blockIdx.x == 0)
         for (uint32_t i = t; i < tail_words; i += K1_THREADS) tail[i] = 0;
-    SGC_TIMELINE_END(dbg, tl_k1, next_free);
+    SGC_TIMELINE_END4(dbg, tl_k1, next_free, k1_ph[0], k1_ph[1], k1_ph[2], k1_ph[3]);
 }
 
 // ------------------------------------------------------------------------------------------------ K2
