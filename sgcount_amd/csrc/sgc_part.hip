@@ -533,9 +533,10 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             const uint32_t hb = wvi / QPB, j0 = (wvi % QPB) * 256u + 4u * (t & 63u);
             const uint32_t nsteps = (nl + BPW - 1u) / BPW;
             const char *const pb = reinterpret_cast<const char *>(pool);
-            // timing-only ablations (-DSGC_ABLATE=1): dbg 1 no pool loads, 2 no table reads, 4 no miss stores, 8 no LDS atomics, 32 the blocks
-            // of a share read from consecutive pool addresses instead of where they are
-#define K2W_ENTRY(s) __builtin_amdgcn_readfirstlane((s) * BPW + hb < nl ? (SGC_DBG(dbg, 32u) ? ((((blockIdx.x * (s_hi - s_lo) + (win - s_lo) + (s) * BPW + hb) % (k1_wgs * blocks_per_wg)) << 11) | (list[(s) * BPW + hb] & 2047u)) : list[(s) * BPW + hb]) : 0xFFFFFFFFu)
+            // timing-only ablations (-DSGC_ABLATE=1; the table is wrong with any of them): dbg 16 the loads alone (every record dropped behind its
+            // load: no unpacking, no LDS, no store), dbg 32 every step reads the share's FIRST blocks again (real records of the slice, served
+            // by the L2: the probe without its HBM traffic), 4 no miss stores
+#define K2W_ENTRY(s) __builtin_amdgcn_readfirstlane((s) * BPW + hb < nl ? list[SGC_DBG(dbg, 32u) ? hb : (s) * BPW + hb] : 0xFFFFFFFFu)
             // (unconditional loads: a lane past the block's fill reads the block's first 16 bytes again — a line that is on its way
             // anyway — and a wave without a block the pool's; loads inside branches make the compiler wait for every load in flight)
 #define K2W_LOAD(e, lo, hi)                                                                                          \
@@ -543,9 +544,8 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 const uint32_t e_ = (e);                                                                             \
                 const char *bb_ = pb + (e_ != 0xFFFFFFFFu ? (uint64_t)(e_ >> 11) * (PART_STRIDE * 8u) : 0ull);       \
                 const uint32_t jj_ = (e_ != 0xFFFFFFFFu && j0 <= (e_ & 2047u)) ? j0 : 0u;                            \
-                if (SGC_DBG(dbg, 1u)) { lo = make_uint4(e_ * 2654435761u + t, e_ * 40503u + t * 77u, e_ + 3u * t, e_ ^ (t << 7)); hi = e_ + t; } else { \
                 lo = *reinterpret_cast<const uint4 *>(bb_ + 4u * jj_);                                               \
-                hi = *reinterpret_cast<const uint32_t *>(bb_ + P6_HI_OFF + jj_); }                                   \
+                hi = *reinterpret_cast<const uint32_t *>(bb_ + P6_HI_OFF + jj_);                                     \
             }
             uint4 clo[WU], nlo[WU];
             uint32_t chi[WU], nhi[WU], ce[WU];
@@ -560,6 +560,7 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
 #pragma unroll
                     for (uint32_t k = 0; k < 4; k++) {
                         const bool valid = ce[u] != 0xFFFFFFFFu && j0 + k <= (ce[u] & 2047u);
+                        if (SGC_DBG(dbg, 16u)) { if (lw[k] == 0x12345678u && chi[u] == 0x9ABCDEFu) local++; continue; }      // (the load must not be optimised away)
                         // five-byte record -> span (as in the narrow loop below)
                         const uint32_t cb = 2u * core_cl, kb = cb - slice_bits;
                         const uint32_t raw_lo = lw[k];
@@ -571,12 +572,12 @@ __global__ void __launch_bounds__(K2_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                         const uint64_t key = (span >> 2) & kmask;
                         const uint32_t h32 = sgc_hash32(key);
                         const uint32_t s1 = h32 >> (32u - ls), s2 = sgc_cuckoo_alt_h(h32, s1, ls);
-                        const uint64_t e1 = SGC_DBG(dbg, 2u) ? (uint64_t)(s1 & 7u ? key : 0ull) : tab1[s1], e2 = SGC_DBG(dbg, 2u) ? 0ull : tab1[s2];
+                        const uint64_t e1 = tab1[s1], e2 = tab1[s2];
                         const bool h2 = e2 == key, hit = e1 == key || h2;
                         const uint32_t slot = h2 ? s2 : s1;
                         const bool hv = valid && hit, mv = valid && !hit;
-                        if (!SGC_DBG(dbg, 8u)) atomicAdd(hv ? &cnt[slot] : &scratch[t & 63u], 1u);
-                        const uint32_t pos = SGC_DBG(dbg, 8u) ? (slot * 7u) % (stretch ? stretch : 1u) : atomicAdd(mv ? &wmiss4[sub] : &scratch[64u + (t & 63u)], 1u);
+                        atomicAdd(hv ? &cnt[slot] : &scratch[t & 63u], 1u);
+                        const uint32_t pos = atomicAdd(mv ? &wmiss4[sub] : &scratch[64u + (t & 63u)], 1u);
                         if (mv && !SGC_DBG(dbg, 4u) && SGC_BOUND(pos < stretch, reinterpret_cast<unsigned long long *>(matched) + 3, 11)) mrun[(uint64_t)run0 + sgc_mul24(sub, stretch) + pos] = span;
                     }
                 }
