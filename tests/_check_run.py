@@ -20,7 +20,9 @@ for n, ng, opts, mode in ((1_000_000, 20_000, {}, 0), (1_000_000, 20_000, {"bala
                           (1_000_000, 20_000, {"five_byte": 0, "six_byte": 0}, 0),
                           (1_000_000, 20_000, {"direct": 0}, 0), (1_000_000, 20_000, {"dense": 0, "cuckoo": 0}, 0), (1_000_000, 20_000, {"variant": 3}, 0),
                           (40_000_000, 100_000, {}, 0), (40_000_000, 100_000, {"place_trials": 4}, 0), (3_000, 300, {}, 0), (1_500_000, 150_000, {}, 0),
-                          (8_000_000, 100_000, {}, DOM), (8_000_000, 100_000, {"balanced": 0}, DOM), (2_000, 100_000, {}, DOM)):
+                          (8_000_000, 100_000, {}, DOM), (8_000_000, 100_000, {"balanced": 0}, DOM), (2_000, 100_000, {}, DOM),
+                          (8_000_000, 100_000, {}, 0), (8_000_000, 100_000, {"wide": 0}, 0),          # the narrow loop of k_count_slices against the wide one
+                          (1_500_000, 250_000, {}, 0), (1_500_000, 250_000, {"cuckoo": 0}, 0)):       # slices of 2^13 slots
     for exact in (False, True):
         wl = DeviceWorkload(n, ng, 20, one_mismatch=not exact, gen_chunk=2_000_000, mode=mode)
         for k, v in opts.items():
