@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <type_traits>
 
 #include "sgc_device.h"
 #include "sgc_format.h"
@@ -193,6 +194,12 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             if (SGC_STAMPS && (dbg & 512)) { tsa = __builtin_amdgcn_s_memtime(); n_it++; }
             const uint64_t rec = r0;
             r0 = r1; r1 = r2; r2 = r3;
+            // Most waves hold nothing but records without a status (the misses of k_count_slices: every window alive, no 'N'): for them the
+            // per-window state (alive / 'N' position / undecidable) is a constant, and the body below is compiled a second time with it folded
+            // away — the kernel is bound by vector issue.  The records with a status (the generic share: an 'N', a dead
+            // window) sit together at the end of a partition, so few waves are mixed; a mixed wave takes the general body.
+            auto body = [&](auto clean_tag) {
+            constexpr bool CLEAN = decltype(clean_tag)::value;
             const uint64_t span = rec & smask;
             const uint32_t status = (uint32_t)(rec >> sh);
             const uint32_t corev = (uint32_t)((span >> cs2) & cmask);
@@ -204,7 +211,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             // vis bit a: window a takes part in this pass; unk bit a: its single-mismatch level cannot be decided
             // here ('N' inside the core); nr_a: the 'N' position as a bit of the rest (0 = clean)
             uint32_t vis = valid ? 7u : 0u, unk = 0, nr0 = 0, nr1 = 0, nr2 = 0, st0 = 0, st1 = 0, st2 = 0;
-            if (status) {
+            if (!CLEAN && status) {
                 // status = sC + K (sP + K sM); n / K as a multiply-shift (exact for n < K^3 <= 2^14, K <= 25: checked
                 // for every such n by tests/test_abi_cpu.py::test_status_division_magic)
                 const uint32_t q1 = (status * kdiv) >> 20;
@@ -234,7 +241,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                     const uint64_t e = ent[i];
                     if (((uint32_t)e & 0x3FFFFFFFu) != corev) continue;          // another core in the same bucket
                     const uint32_t a = (uint32_t)e >> 30;
-                    if (!((vis >> a) & 1u)) continue;
+                    if (!CLEAN && !((vis >> a) & 1u)) continue;          // (a clean record inside this loop is valid: all three windows take part)
                     const uint32_t Ra = a == 0 ? R0 : (a == 1 ? R1 : R2), nr = a == 0 ? nr0 : (a == 1 ? nr1 : nr2);
                     const uint32_t x = Ra ^ (uint32_t)(e >> 32);
                     const uint32_t dm = ((x | (x >> 1)) & 0x55555555u) & ~nr;
@@ -255,9 +262,9 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             uint32_t lm = (ex1 != SGC_NONE ? 1u : 0u) | (!EXACT && cC == 1 ? 2u : 0u) | (ex2 != SGC_NONE ? 4u : 0u) | (!EXACT && cP == 1 ? 8u : 0u) |
                           (ex0 != SGC_NONE ? 16u : 0u) | (!EXACT && cM == 1 ? 32u : 0u);
             const uint32_t um = EXACT ? 0u :
-                                ((((vis >> 1) & 1u) && cC == 0 && !nr1) || (unk & 2u) ? 2u : 0u) |
-                                ((((vis >> 2) & 1u) && cP == 0 && !nr2) || (unk & 4u) ? 8u : 0u) |
-                                (((vis & 1u) && cM == 0 && !nr0) || (unk & 1u) ? 32u : 0u);
+                                (((CLEAN ? valid : ((vis >> 1) & 1u) != 0) && cC == 0 && !nr1) || (unk & 2u) ? 2u : 0u) |
+                                (((CLEAN ? valid : ((vis >> 2) & 1u) != 0) && cP == 0 && !nr2) || (unk & 4u) ? 8u : 0u) |
+                                (((CLEAN ? valid : (vis & 1u) != 0) && cM == 0 && !nr0) || (unk & 1u) ? 32u : 0u);
             uint32_t lvl = 6, res = SGC_NONE;
             while (lm) {
                 lvl = (uint32_t)__builtin_ctz(lm);
@@ -342,6 +349,8 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 }
             }
             if (SGC_STAMPS && (dbg & 512)) { const unsigned long long x = __builtin_amdgcn_s_memtime(); ts_out += x - tsa; }
+            };
+            if (__ballot((uint32_t)(rec >> sh) != 0) == 0ull) body(std::true_type{}); else body(std::false_type{});
         }
         KC_PHASE(tp_iter)
     }
