@@ -666,9 +666,13 @@ def main():
     dev_index = local_rank % max(n_dev, 1)          # one rank per GPU on a full node; ranks share a card only in rehearsals
     torch.cuda.set_device(dev_index)
     backend = os.environ.get("SGC_BENCH_BACKEND", "nccl")   # "gloo": rehearse the N > 1 flow on a box with fewer GPUs
+    cpu_group = None
     if world > 1:
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+            # a host-side group for the one wait that must not occupy the devices: while rank 0 runs the multi-sample command line over
+            # all N devices the other ranks wait here, not inside a device-side barrier kernel
+            cpu_group = dist.new_group(backend="gloo")
         else:
             dist.init_process_group(backend=backend)
 
@@ -903,6 +907,8 @@ def main():
         print(json.dumps(out), flush=True)
     wl.close()
     if world > 1:
+        if cpu_group is not None:
+            dist.barrier(group=cpu_group)
         dist.barrier()
         dist.destroy_process_group()
 

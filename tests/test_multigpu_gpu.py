@@ -46,6 +46,10 @@ def test_bench_self_launch_two_ranks_gloo_rehearsal():
     # same per-rank workload: rank 0's sample is the N = 1 sample, so the matched fraction agrees exactly
     assert two["matched_fraction"] == one["matched_fraction"]
     assert two["config"]["reads_per_gpu"] == 3000000 and two["scaling"] == "weak"
+    # N > 1: rank 0 also runs N samples through ONE command line dealt to the N devices (here: both to the one card), the host-bound curve
+    ms = two["e2e"]["multi_sample"]
+    assert ms["samples"] == 2 and ms["worker_threads"] == 2 and ms["reads_counted"] == [1500000, 1500000], ms
+    assert ms["reads_per_s"] > 0 and len(ms["sample_s"]) == 2
 
 
 def test_bench_two_ranks_rccl():
