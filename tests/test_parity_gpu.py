@@ -111,6 +111,18 @@ def test_unsupported_library_fails_loudly(S):
     assert e.value.code == ffi.E_UNSUPPORTED
 
 
+def test_option_values_are_checked(S):
+    """the retired variants (0: direct atomics, 2: the superseded lookup kernel) and slice sizes the kernels do not have are refused"""
+    ffi = S._ffi
+    dl = _lib(S, b">a\nACGTACGTACGTACGTACGT\n>b\nTTGTACGTACGTACGTACGA\n").device(True)
+    for key, bad in (("variant", 0), ("variant", 2), ("variant", 5), ("slice_log2", 11), ("slice_log2", 14)):
+        with pytest.raises(ffi.SgcError) as e:
+            dl.set_option(key, bad)
+        assert e.value.code == ffi.E_ARG, (key, bad)
+    for key, ok in (("variant", 1), ("variant", 3), ("variant", 4), ("slice_log2", 12), ("slice_log2", 13), ("slice_log2", 0), ("wide", 0), ("wide", 1)):
+        dl.set_option(key, ok)
+
+
 # ---- example/ fixtures vs committed golden tables -------------------------------------------------
 @pytest.mark.parametrize("pack", ["host", "device"])
 def test_example_fixtures_golden(S, pack, example_library_text, example_reads):
