@@ -49,6 +49,9 @@
 #define KC_THREADS 1024u
 #define KC_CHUNK 4096u           // records per unit of resolver work
 #define KC_GRID 512u
+#ifndef KC_ALTPRIO
+#define KC_ALTPRIO 1
+#endif
 
 // tot[] (records per partition) -> ps[p] = first record of partition p (ps[P] = total) and cs[p] = first
 // KC_CHUNK-record chunk of partition p (cs[P] = number of chunks); ps/cs: LDS arrays of P + 1 entries
@@ -129,6 +132,13 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
 #define KC_PHASE(acc) if (SGC_STAMPS && (dbg & 1048576u)) { const unsigned long long x_ = __builtin_amdgcn_s_memtime(); acc += x_ - tp_x; tp_x = x_; }
     uint32_t n_it = 0;
     for (uint32_t ch = c_lo; ch < c_hi; ch++) {
+#if KC_ALTPRIO
+        // The two workgroups of a CU are not served alike: the issue arbiter prefers the older one, which then finishes a quarter of the
+        // kernel's time before the younger (the timelines of round 3) and leaves it to run alone, at 0.75 of the pair's rate.  Taking
+        // turns at the higher priority, chunk by chunk and in opposite phase, lets both advance alike: pass B 0.050 -> 0.046 ms, pass A
+        // 0.197 -> 0.196 (per record iteration instead: pass A 0.200; the same in k_partition / k_count_slices: lost in their process-to-process spread).
+        if ((((ch - c_lo) & 1u) ^ (blockIdx.x >= gridDim.x / 2u ? 1u : 0u)) != 0u) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
         const uint32_t p = find_extent<SGC_CORE_MAX_LOG2_P>(cs_, P, ch);
         if (p != cur_p) {                                    // uniform over the workgroup
             __syncthreads();
