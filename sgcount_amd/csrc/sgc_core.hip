@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
                 lvl = 6; res = SGC_NONE;
             }
             uint32_t unk_above = um & ((1u << lvl) - 1u);
-            if (!FINAL && unk_above && cv.filt) {
+            if (!FINAL && unk_above && cv.filt && !SGC_DBG(dbg, 16384u)) {
                 // a clean window that saw no candidate here: a clear bit of the rest filter proves that no parent hides
                 // inside the core either ('N' inside the core — unk — stays undecided)
                 const uint32_t cand = unk_above & ~(((unk & 2u) ? 2u : 0u) | ((unk & 4u) ? 8u : 0u) | ((unk & 1u) ? 32u : 0u));
@@ -360,6 +360,9 @@ __global__ void __launch_bounds__(KC_THREADS, 8) __attribute__((amdgpu_num_sgpr(
             }
             if (SGC_STAMPS && (dbg & 512)) { const unsigned long long x = __builtin_amdgcn_s_memtime(); ts_out += x - tsa; }
             };
+            // (timing-only ablations, -DSGC_ABLATE=1: dbg 32768 the records are loaded and dropped — the kernel's skeleton: staging, chunk
+            // prologues, loads, epilogue; 16384 no rest filter; 1024 no bucket scan; 2048 no ambiguity masks; 4096 no forwards; 8192 no flush)
+            if (SGC_DBG(dbg, 32768u)) { if (rec == 0x123456789ABCDEFull) local++; continue; }
             if (__ballot((uint32_t)(rec >> sh) != 0) == 0ull) body(std::true_type{}); else body(std::false_type{});
         }
         KC_PHASE(tp_iter)
