@@ -52,6 +52,43 @@ def test_bench_self_launch_two_ranks_gloo_rehearsal():
     assert ms["reads_per_s"] > 0 and len(ms["sample_s"]) == 2
 
 
+RCCL_ONE_RANK = r"""
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch, torch.distributed as dist
+from sgcount_amd.workload import DeviceWorkload
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%%d" %% int(sys.argv[1]), world_size=1, rank=0,
+                        device_id=torch.device("cuda", 0))
+wl = DeviceWorkload(200000, 2000, 20, one_mismatch=True)
+row = torch.zeros(2002, dtype=torch.int64, device=wl.dev)
+wl.step(out=row)                                                  # our kernels and the collectives on one stream
+gathered = torch.empty((1, 2002), dtype=torch.int64, device=wl.dev)
+dist.all_gather_into_tensor(gathered.view(-1), row)               # the exchange of bench.py --gpus N, over RCCL
+summed = row.clone()
+dist.all_reduce(summed, op=dist.ReduceOp.SUM)                     # the within-sample reduce of sgcount_amd.distributed
+dist.barrier()
+torch.cuda.synchronize()
+counts, total, matched = wl.result(row)
+assert total == 200000 and 0 < matched <= total and int(counts.sum()) == matched
+assert torch.equal(gathered[0], row) and torch.equal(summed, row)
+dist.destroy_process_group()
+print("rccl ok", total, matched)
+"""
+
+
+def test_rccl_collectives_on_one_rank():
+    """What a one-GPU box can show of the RCCL path: the process group comes up on the device, and the two collectives the N > 1 flows use
+    (all-gather of the count rows, sum of partial rows) run on the stream our kernels ran on and leave the row intact."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-c", RCCL_ONE_RANK % ROOT, str(port)], capture_output=True, timeout=300, env=env)
+    assert p.returncode == 0 and b"rccl ok 200000" in p.stdout, (p.stdout.decode()[-500:], p.stderr.decode()[-2000:])
+
+
 def test_bench_two_ranks_rccl():
     import torch
     if torch.cuda.device_count() < 2:
