@@ -1,61 +1,37 @@
-"""Two batches in flight: does a pass overlap with the next one when they run on two contexts / two streams?
-k_partition is bound by memory, the resolver by its vector units and latency chains, and one workgroup of each fits on a CU
-(LDS 79 + 58 KiB, 16 + 16 waves): alternate the passes of a resident sample between two contexts and compare with the same
-number of passes on one.  usage (GPU box): python tools/overlap_probe.py [--reads N] [--steps K] [--workload 1mm|exact]"""
-import argparse
-import os
-import sys
-import time
-
+#!/usr/bin/env python3
+"""Do two half-size count passes on two streams overlap on one GPU?  (feasibility probe for splitting a pass in two)
+python tools/overlap_probe.py"""
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-
+import torch
+from sgcount_amd.workload import DeviceWorkload
+from sgcount_amd import synth
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--reads", type=int, default=100_000_000)
-    ap.add_argument("--guides", type=int, default=100_000)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--rounds", type=int, default=3)
-    ap.add_argument("--workload", choices=["1mm", "exact"], default="1mm")
-    ap.add_argument("--contexts", type=int, default=2)
-    args = ap.parse_args()
-    import torch
-    from sgcount_amd.workload import DeviceWorkload
-    wls = [DeviceWorkload(args.reads, args.guides, 20, one_mismatch=args.workload == "1mm")]
-    streams = [torch.cuda.current_stream()]
-    for k in range(1, args.contexts):
-        s = torch.cuda.Stream()
-        with torch.cuda.stream(s):
-            w = DeviceWorkload(1, args.guides, 20, one_mismatch=args.workload == "1mm")
-        w.n_reads, w.records = wls[0].n_reads, wls[0].records          # the same resident sample
-        w.dl.set_stream(s.cuda_stream)
-        wls.append(w); streams.append(s)
+    n = 100_000_000
+    full = DeviceWorkload(n, 100_000, 20, one_mismatch=True)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    halves = []
+    for k, st in enumerate((s1, s2)):
+        with torch.cuda.stream(st):
+            w = DeviceWorkload(n // 2, 100_000, 20, one_mismatch=True, reads_seed=synth.READS_SEED + 7 * k)
+            w.dl.set_stream(st.cuda_stream)
+            halves.append(w)
     torch.cuda.synchronize()
-
-    def run(n_ctx, steps):
-        for w in wls[:n_ctx]:
-            w.step()
+    def timeit(fn, reps=10):
+        fn(); torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            wls[i % n_ctx].step()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / steps * 1e3
+        return (time.perf_counter() - t) / reps * 1e3
+    print("one 100M pass            : %.3f ms" % timeit(lambda: full.step()))
+    print("one 50M pass             : %.3f ms" % timeit(lambda: halves[0].step()))
+    def both():
+        halves[0].step(); halves[1].step()
+    print("two 50M passes, 2 streams: %.3f ms" % timeit(both))
+    def seq():
+        halves[0].step(); torch.cuda.synchronize(); halves[1].step(); torch.cuda.synchronize()
+    print("two 50M passes, serial   : %.3f ms" % timeit(seq))
 
-    want = None
-    for r in range(args.rounds):
-        line = []
-        for n_ctx in range(1, args.contexts + 1):
-            ms = run(n_ctx, args.steps)
-            line.append("%d in flight: %.3f ms per pass (%.1f G reads/s)" % (n_ctx, ms, args.reads / ms / 1e6))
-        print("   ".join(line), flush=True)
-    for w in wls:
-        c, total, matched = w.result()
-        if want is None:
-            want = (c.tobytes(), total, matched)
-        assert (c.tobytes(), total, matched) == want, "the contexts disagree"
-    print("tables equal: total %d matched %d" % (want[1], want[2]))
-
-
-if __name__ == "__main__":
-    main()
+main()
